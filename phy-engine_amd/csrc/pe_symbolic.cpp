@@ -1,0 +1,666 @@
+// pe_symbolic.cpp -- see pe_symbolic.hpp.
+//
+// Index conventions.  A is the n x n MNA matrix in CSR.  The factorisation works on
+//     A''[k][l] = A[ row_src[k] ][ col_src[l] ]
+// i.e. permuted equation k is original equation row_src[k] and permuted unknown l is original unknown
+// col_src[l].  row_src = rmatch o q and col_src = q, where rmatch is the row matching (equation chosen as
+// pivot row for each unknown) and q the fill-reducing symmetric ordering of pattern(A' + A'^T),
+// A'[j][:] = A[rmatch[j]][:].
+#include "pe_symbolic.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace pe
+{
+    namespace
+    {
+        using ivec = std::vector<int>;
+
+        // ------------------------------------------------------------------------------------
+        // 1. row matching: unknown j <- equation rmatch[j], maximising (greedily) the scaled pivot size
+        // ------------------------------------------------------------------------------------
+        bool match_rows(int n, int const* rp, int const* ci, double const* vals, double diag_rel, ivec& rmatch, int& swaps)
+        {
+            rmatch.assign(n, -1);
+            ivec colof(n, -1);  // equation i -> unknown it pivots
+            std::vector<double> rowmax(n, 0.0);
+            for(int i = 0; i < n; ++i)
+                for(int e = rp[i]; e < rp[i + 1]; ++e) rowmax[i] = std::max(rowmax[i], vals ? std::fabs(vals[e]) : 1.0);
+            // pass 1: keep the diagonal wherever it is usable
+            for(int i = 0; i < n; ++i)
+            {
+                for(int e = rp[i]; e < rp[i + 1]; ++e)
+                {
+                    if(ci[e] != i) continue;
+                    double const w = vals ? std::fabs(vals[e]) : 1.0;
+                    if(w > 0.0 && w >= diag_rel * rowmax[i])
+                    {
+                        rmatch[i] = i;
+                        colof[i] = i;
+                    }
+                }
+            }
+            // pass 2: augmenting paths for the remaining equations, heaviest (row-scaled) candidates first
+            std::vector<ivec> cand(n);
+            auto build_cand = [&](int i)
+            {
+                if(!cand[i].empty()) return;
+                std::vector<std::pair<double, int>> t;
+                for(int e = rp[i]; e < rp[i + 1]; ++e)
+                {
+                    double const w = vals ? std::fabs(vals[e]) : 1.0;
+                    if(w > 0.0) t.push_back({-w, ci[e]});
+                }
+                std::sort(t.begin(), t.end());
+                for(auto const& [w, c]: t) cand[i].push_back(c);
+            };
+            ivec visited(n, -1), it(n, 0), stack_row, stack_col;
+            for(int r0 = 0; r0 < n; ++r0)
+            {
+                if(colof[r0] >= 0) continue;
+                // iterative DFS over alternating paths: equation -> candidate unknown -> equation currently holding it
+                stack_row.assign(1, r0);
+                stack_col.clear();
+                build_cand(r0);
+                it[r0] = 0;
+                bool found = false;
+                while(!stack_row.empty())
+                {
+                    int const i = stack_row.back();
+                    if(it[i] >= static_cast<int>(cand[i].size()))
+                    {
+                        stack_row.pop_back();
+                        if(!stack_col.empty()) stack_col.pop_back();
+                        continue;
+                    }
+                    int const c = cand[i][it[i]++];
+                    if(visited[c] == r0) continue;
+                    visited[c] = r0;
+                    stack_col.push_back(c);
+                    if(rmatch[c] < 0)
+                    {
+                        found = true;
+                        break;
+                    }
+                    int const nxt = rmatch[c];
+                    build_cand(nxt);
+                    it[nxt] = 0;
+                    stack_row.push_back(nxt);
+                }
+                if(!found) return false;  // structurally singular
+                // flip along the path: stack_row[t] takes stack_col[t]
+                for(size_t t = 0; t < stack_row.size(); ++t)
+                {
+                    rmatch[stack_col[t]] = stack_row[t];
+                    colof[stack_row[t]] = stack_col[t];
+                }
+            }
+            swaps = 0;
+            for(int j = 0; j < n; ++j) swaps += rmatch[j] != j;
+            return true;
+        }
+
+        // ------------------------------------------------------------------------------------
+        // 2. adjacency of pattern(A' + A'^T), no diagonal
+        // ------------------------------------------------------------------------------------
+        void sym_graph(int n, int const* rp, int const* ci, ivec const& rmatch, ivec& gp, ivec& gi)
+        {
+            std::vector<ivec> adj(n);
+            for(int j = 0; j < n; ++j)
+            {
+                int const r = rmatch[j];
+                for(int e = rp[r]; e < rp[r + 1]; ++e)
+                {
+                    int const c = ci[e];
+                    if(c == j) continue;
+                    adj[j].push_back(c);
+                    adj[c].push_back(j);
+                }
+            }
+            gp.assign(n + 1, 0);
+            for(int v = 0; v < n; ++v)
+            {
+                std::sort(adj[v].begin(), adj[v].end());
+                adj[v].erase(std::unique(adj[v].begin(), adj[v].end()), adj[v].end());
+                gp[v + 1] = gp[v] + static_cast<int>(adj[v].size());
+            }
+            gi.resize(gp[n]);
+            for(int v = 0; v < n; ++v) std::copy(adj[v].begin(), adj[v].end(), gi.begin() + gp[v]);
+        }
+
+        // ------------------------------------------------------------------------------------
+        // 3. nested dissection by BFS level sets, minimum degree on the leaves
+        // ------------------------------------------------------------------------------------
+        struct Dissector
+        {
+            int n;
+            ivec const& gp;
+            ivec const& gi;
+            int leaf;
+            ivec tag, level, order;
+            int next_tag{1};
+
+            Dissector(int n_, ivec const& gp_, ivec const& gi_, int leaf_) : n(n_), gp(gp_), gi(gi_), leaf(leaf_), tag(n_, 0), level(n_, 0) { order.reserve(n_); }
+
+            // exact minimum degree on the induced subgraph of V (|V| small)
+            void md_leaf(ivec const& V)
+            {
+                int const k = static_cast<int>(V.size());
+                if(k == 0) return;
+                int const t = next_tag++;
+                ivec local(k);
+                for(int a = 0; a < k; ++a)
+                {
+                    tag[V[a]] = t;
+                    level[V[a]] = a;  // reuse as local id
+                }
+                std::vector<std::vector<char>> adj(k, std::vector<char>(k, 0));
+                for(int a = 0; a < k; ++a)
+                    for(int e = gp[V[a]]; e < gp[V[a] + 1]; ++e)
+                        if(tag[gi[e]] == t) adj[a][level[gi[e]]] = 1;
+                std::vector<char> gone(k, 0);
+                for(int step = 0; step < k; ++step)
+                {
+                    int best = -1, bestd = 1 << 30;
+                    for(int a = 0; a < k; ++a)
+                    {
+                        if(gone[a]) continue;
+                        int d = 0;
+                        for(int b = 0; b < k; ++b) d += (!gone[b] && adj[a][b]);
+                        if(d < bestd)
+                        {
+                            bestd = d;
+                            best = a;
+                        }
+                    }
+                    gone[best] = 1;
+                    order.push_back(V[best]);
+                    for(int a = 0; a < k; ++a)
+                    {
+                        if(gone[a] || !adj[best][a]) continue;
+                        for(int b = 0; b < k; ++b)
+                            if(!gone[b] && b != a && adj[best][b]) adj[a][b] = 1;
+                    }
+                }
+            }
+
+            // BFS inside the tagged set from `start`; fills `out` (visit order) and level[]; returns eccentricity
+            int bfs(int start, int t, int mark, ivec& out, ivec& seen)
+            {
+                out.clear();
+                out.push_back(start);
+                seen[start] = mark;
+                level[start] = 0;
+                size_t head = 0;
+                int ecc = 0;
+                while(head < out.size())
+                {
+                    int const v = out[head++];
+                    for(int e = gp[v]; e < gp[v + 1]; ++e)
+                    {
+                        int const w = gi[e];
+                        if(tag[w] != t || seen[w] == mark) continue;
+                        seen[w] = mark;
+                        level[w] = level[v] + 1;
+                        ecc = level[w];
+                        out.push_back(w);
+                    }
+                }
+                return ecc;
+            }
+
+            ivec seen;
+            int next_mark{1};
+
+            void run(ivec V)
+            {
+                if(seen.empty()) seen.assign(n, 0);
+                if(static_cast<int>(V.size()) <= leaf)
+                {
+                    md_leaf(V);
+                    return;
+                }
+                int const t = next_tag++;
+                for(int v: V) tag[v] = t;
+                ivec reach;
+                int ecc = bfs(V[0], t, next_mark++, reach, seen);
+                if(reach.size() < V.size())
+                {
+                    // disconnected: dissect the components independently
+                    int const mk = next_mark - 1;
+                    ivec rest;
+                    for(int v: V)
+                        if(seen[v] != mk) rest.push_back(v);
+                    ivec comp = reach;
+                    run(std::move(comp));
+                    run(std::move(rest));
+                    return;
+                }
+                // pseudo-peripheral start: restart from a minimum-degree vertex of the last level while the depth grows
+                for(int rounds = 0; rounds < 6; ++rounds)
+                {
+                    int far = reach.back(), fard = 1 << 30;
+                    for(size_t a = reach.size(); a-- > 0 && level[reach[a]] == ecc;)
+                    {
+                        int const d = gp[reach[a] + 1] - gp[reach[a]];
+                        if(d < fard)
+                        {
+                            fard = d;
+                            far = reach[a];
+                        }
+                    }
+                    ivec r2;
+                    int const e2 = bfs(far, t, next_mark++, r2, seen);
+                    if(e2 > ecc)
+                    {
+                        ecc = e2;
+                        reach.swap(r2);
+                    }
+                    else
+                    {
+                        // keep the deeper (current `reach`) structure: recompute its levels (bfs overwrote level[])
+                        int const s0 = reach[0];
+                        ecc = bfs(s0, t, next_mark++, reach, seen);
+                        break;
+                    }
+                }
+                if(ecc < 2)
+                {
+                    md_leaf(V);
+                    return;
+                }
+                // level sizes -> most balanced interior level
+                ivec cnt(ecc + 1, 0);
+                for(int v: reach) ++cnt[level[v]];
+                long long below = cnt[0];
+                long long const total = static_cast<long long>(reach.size());
+                int best_m = 1;
+                double best_cost = 1e300;
+                for(int m = 1; m < ecc; ++m)
+                {
+                    long long const above = total - below - cnt[m];
+                    double const cost = static_cast<double>(std::max(below, above)) + 0.5 * cnt[m];
+                    if(cost < best_cost)
+                    {
+                        best_cost = cost;
+                        best_m = m;
+                    }
+                    below += cnt[m];
+                }
+                ivec A, B, S;
+                for(int v: reach)
+                {
+                    if(level[v] < best_m) A.push_back(v);
+                    else if(level[v] > best_m) B.push_back(v);
+                    else
+                    {
+                        bool touches = false;
+                        for(int e = gp[v]; e < gp[v + 1] && !touches; ++e)
+                            touches = tag[gi[e]] == t && level[gi[e]] == best_m + 1;
+                        (touches ? S : A).push_back(v);
+                    }
+                }
+                run(std::move(A));
+                run(std::move(B));
+                for(int v: S) order.push_back(v);
+            }
+        };
+
+        // ------------------------------------------------------------------------------------
+        // 4. elimination tree / postorder / column structures
+        // ------------------------------------------------------------------------------------
+        void etree_of(int n, std::vector<ivec> const& lower /* lower[i] = {k < i : B[i][k] != 0} */, ivec& parent)
+        {
+            parent.assign(n, -1);
+            ivec anc(n, -1);
+            for(int i = 0; i < n; ++i)
+            {
+                for(int k0: lower[i])
+                {
+                    int k = k0;
+                    while(k != -1 && k < i)
+                    {
+                        int const nxt = anc[k];
+                        anc[k] = i;
+                        if(nxt == -1)
+                        {
+                            parent[k] = i;
+                            break;
+                        }
+                        k = nxt;
+                    }
+                }
+            }
+        }
+
+        void col_structs(int n, std::vector<ivec> const& upper /* upper[j] = {i > j : B[i][j] != 0} sorted */, ivec const& parent, std::vector<ivec>& st)
+        {
+            st.assign(n, {});
+            std::vector<ivec> kids(n);
+            for(int j = 0; j < n; ++j)
+                if(parent[j] >= 0) kids[parent[j]].push_back(j);
+            ivec mark(n, -1);
+            for(int j = 0; j < n; ++j)
+            {
+                ivec& s = st[j];
+                for(int i: upper[j])
+                    if(mark[i] != j)
+                    {
+                        mark[i] = j;
+                        s.push_back(i);
+                    }
+                for(int c: kids[j])
+                    for(int i: st[c])
+                        if(i != j && mark[i] != j)
+                        {
+                            mark[i] = j;
+                            s.push_back(i);
+                        }
+                std::sort(s.begin(), s.end());
+            }
+        }
+    }  // namespace
+
+    bool analyze(int n, int const* rp, int const* ci, double const* vals, SymbolicOptions const& opt, Symbolic& S)
+    {
+        S = Symbolic{};
+        S.n = n;
+        S.nnzA = rp[n];
+        if(n == 0) return true;
+
+        ivec rmatch;
+        if(!match_rows(n, rp, ci, vals, opt.match_diag_rel, rmatch, S.n_row_swaps))
+        {
+            S.structurally_singular = true;
+            S.error = "structurally singular matrix (no zero-free diagonal exists)";
+            return false;
+        }
+
+        ivec gp, gi;
+        sym_graph(n, rp, ci, rmatch, gp, gi);
+
+        ivec q;
+        {
+            Dissector D(n, gp, gi, std::max(2, opt.nd_leaf));
+            ivec all(n);
+            std::iota(all.begin(), all.end(), 0);
+            D.run(std::move(all));
+            q = std::move(D.order);
+        }
+        if(static_cast<int>(q.size()) != n)
+        {
+            S.error = "internal: ordering lost vertices";
+            return false;
+        }
+
+        // two passes: (a) etree + structures in ordering q, (b) postorder with the heaviest child last, redo
+        std::vector<ivec> st;
+        ivec parent;
+        for(int pass = 0; pass < 2; ++pass)
+        {
+            ivec qinv(n);
+            for(int k = 0; k < n; ++k) qinv[q[k]] = k;
+            std::vector<ivec> lower(n), upper(n);
+            for(int k = 0; k < n; ++k)
+            {
+                int const v = q[k];
+                for(int e = gp[v]; e < gp[v + 1]; ++e)
+                {
+                    int const l = qinv[gi[e]];
+                    if(l < k) lower[k].push_back(l);
+                    else upper[k].push_back(l);
+                }
+                std::sort(upper[k].begin(), upper[k].end());
+            }
+            etree_of(n, lower, parent);
+            col_structs(n, upper, parent, st);
+            if(pass == 1) break;
+            // postorder, children sorted by structure size ascending (largest last => mergeable with the parent)
+            std::vector<ivec> kids(n);
+            ivec roots;
+            for(int j = 0; j < n; ++j) (parent[j] >= 0 ? kids[parent[j]] : roots).push_back(j);
+            auto by_size = [&](int a, int b) { return st[a].size() != st[b].size() ? st[a].size() < st[b].size() : a < b; };
+            for(auto& kv: kids) std::sort(kv.begin(), kv.end(), by_size);
+            ivec post;
+            post.reserve(n);
+            ivec stack, itx(n, 0);
+            for(int r: roots)
+            {
+                stack.push_back(r);
+                while(!stack.empty())
+                {
+                    int const v = stack.back();
+                    if(itx[v] < static_cast<int>(kids[v].size())) stack.push_back(kids[v][itx[v]++]);
+                    else
+                    {
+                        post.push_back(v);
+                        stack.pop_back();
+                    }
+                }
+            }
+            ivec q2(n);
+            for(int k = 0; k < n; ++k) q2[k] = q[post[k]];
+            q.swap(q2);
+        }
+
+        // ---------------- supernodes: fundamental runs, split at max_pivots, then relaxed merging of last children
+        struct SN
+        {
+            int c0, c1;         // columns [c0, c1)
+            long long zeros;    // explicit zeros in the L panel (same count in U)
+        };
+        std::vector<SN> sn;
+        auto u_of = [&](SN const& s) { return static_cast<int>(st[s.c1 - 1].size()); };
+        auto try_merge = [&](SN& P)
+        {
+            while(!sn.empty())
+            {
+                SN const& C = sn.back();
+                if(C.c1 != P.c0) break;
+                int const pc = parent[C.c1 - 1];
+                if(pc < P.c0 || pc >= P.c1) break;  // not a child of P
+                int const pC = C.c1 - C.c0, uC = u_of(C);
+                int const pP = P.c1 - P.c0, mP = pP + u_of(P);
+                int const np = pC + pP;
+                if(np > opt.max_pivots) break;
+                long long const z = C.zeros + P.zeros + static_cast<long long>(pC) * (mP - uC);
+                double const panel = static_cast<double>(np) * (np + u_of(P)) - 0.5 * np * (np - 1);
+                if(np > opt.relax_small && static_cast<double>(z) > opt.relax_zero_frac * panel) break;
+                P.c0 = C.c0;
+                P.zeros = z;
+                sn.pop_back();
+            }
+        };
+        {
+            int j = 0;
+            while(j < n)
+            {
+                SN P{j, j + 1, 0};
+                while(P.c1 < n && parent[P.c1 - 1] == P.c1 && st[P.c1 - 1].size() == st[P.c1].size() + 1 && (P.c1 - P.c0) < opt.max_pivots) ++P.c1;
+                j = P.c1;
+                try_merge(P);
+                sn.push_back(P);
+            }
+        }
+
+        // ---------------- fronts
+        int const nf = static_cast<int>(sn.size());
+        S.nfronts = nf;
+        S.f_col0.resize(nf);
+        S.f_p.resize(nf);
+        S.f_u.resize(nf);
+        S.f_parent.assign(nf, -1);
+        S.f_rows_ptr.assign(nf + 1, 0);
+        ivec col2front(n);
+        for(int s = 0; s < nf; ++s)
+        {
+            S.f_col0[s] = sn[s].c0;
+            S.f_p[s] = sn[s].c1 - sn[s].c0;
+            S.f_u[s] = u_of(sn[s]);
+            S.f_rows_ptr[s + 1] = S.f_rows_ptr[s] + S.f_u[s];
+            for(int c = sn[s].c0; c < sn[s].c1; ++c) col2front[c] = s;
+            S.nnz_LU_stored += 2LL * S.f_p[s] * S.f_u[s] + static_cast<long long>(S.f_p[s]) * S.f_p[s];
+        }
+        S.f_rows.resize(S.f_rows_ptr[nf]);
+        for(int s = 0; s < nf; ++s)
+        {
+            auto const& r = st[sn[s].c1 - 1];
+            std::copy(r.begin(), r.end(), S.f_rows.begin() + S.f_rows_ptr[s]);
+            if(!r.empty()) S.f_parent[s] = col2front[r[0]];
+            int const m = S.f_p[s] + S.f_u[s];
+            S.max_m = std::max(S.max_m, m);
+            S.max_u = std::max(S.max_u, S.f_u[s]);
+            for(int k = 0; k < S.f_p[s]; ++k)
+            {
+                double const r1 = m - k - 1;
+                S.flops += 2.0 * r1 * r1 + r1;
+            }
+        }
+        for(int j = 0; j < n; ++j) S.nnz_LU += 2LL * static_cast<long long>(st[j].size()) + 1;
+        if(S.max_m >= 65536)
+        {
+            S.error = "front order exceeds 65535";
+            return false;
+        }
+
+        auto local_of = [&](int s, int t) -> int
+        {
+            int const c0 = S.f_col0[s], p = S.f_p[s];
+            if(t < c0 + p) return t - c0;
+            auto b = S.f_rows.begin() + S.f_rows_ptr[s], e = S.f_rows.begin() + S.f_rows_ptr[s + 1];
+            auto it = std::lower_bound(b, e, t);
+            if(it == e || *it != t) return -1;
+            return p + static_cast<int>(it - b);
+        };
+
+        // children, relative indices, depth
+        S.f_child_ptr.assign(nf + 1, 0);
+        for(int s = 0; s < nf; ++s)
+            if(S.f_parent[s] >= 0) ++S.f_child_ptr[S.f_parent[s] + 1];
+        for(int s = 0; s < nf; ++s) S.f_child_ptr[s + 1] += S.f_child_ptr[s];
+        S.f_child.resize(S.f_child_ptr[nf]);
+        {
+            ivec fill(S.f_child_ptr.begin(), S.f_child_ptr.end() - 1);
+            for(int s = 0; s < nf; ++s)
+                if(S.f_parent[s] >= 0) S.f_child[fill[S.f_parent[s]]++] = s;
+        }
+        S.f_rel_ptr = S.f_rows_ptr;
+        S.f_rel.assign(S.f_rows.size(), -1);
+        {
+            ivec depth(nf, 1);
+            for(int s = nf - 1; s >= 0; --s)
+            {
+                int const P = S.f_parent[s];
+                if(P >= 0)
+                {
+                    depth[s] = depth[P] + 1;
+                    if(P <= s)
+                    {
+                        S.error = "internal: front tree is not in postorder";
+                        return false;
+                    }
+                    for(int a = S.f_rows_ptr[s]; a < S.f_rows_ptr[s + 1]; ++a)
+                    {
+                        int const l = local_of(P, S.f_rows[a]);
+                        if(l < 0)
+                        {
+                            S.error = "internal: child update row missing from parent front";
+                            return false;
+                        }
+                        S.f_rel[a] = l;
+                    }
+                }
+                S.tree_depth = std::max(S.tree_depth, depth[s]);
+            }
+        }
+
+        // permutations
+        S.col_src = q;
+        S.row_src.resize(n);
+        for(int k = 0; k < n; ++k) S.row_src[k] = rmatch[q[k]];
+
+        // assembly lists: A slot e=(i_old, j_old) -> permuted (k, l) -> owner front = front of min(k, l)
+        {
+            ivec qinv(n), eq2k(n);
+            for(int k = 0; k < n; ++k) qinv[q[k]] = k;
+            for(int k = 0; k < n; ++k) eq2k[S.row_src[k]] = k;
+            S.f_asm_ptr.assign(nf + 1, 0);
+            int const nnz = rp[n];
+            ivec owner(nnz), pos(nnz);
+            for(int i = 0; i < n; ++i)
+            {
+                int const k = eq2k[i];
+                for(int e = rp[i]; e < rp[i + 1]; ++e)
+                {
+                    int const l = qinv[ci[e]];
+                    int const s = col2front[std::min(k, l)];
+                    int const r = local_of(s, k), c = local_of(s, l);
+                    if(r < 0 || c < 0)
+                    {
+                        S.error = "internal: matrix entry outside its front";
+                        return false;
+                    }
+                    owner[e] = s;
+                    pos[e] = (r << 16) | c;
+                    ++S.f_asm_ptr[s + 1];
+                }
+            }
+            for(int s = 0; s < nf; ++s) S.f_asm_ptr[s + 1] += S.f_asm_ptr[s];
+            S.asm_slot.resize(nnz);
+            S.asm_pos.resize(nnz);
+            ivec fill(S.f_asm_ptr.begin(), S.f_asm_ptr.end() - 1);
+            for(int e = 0; e < nnz; ++e)
+            {
+                int const d = fill[owner[e]]++;
+                S.asm_slot[d] = e;
+                S.asm_pos[d] = pos[e];
+            }
+        }
+
+        // storage offsets: factor panels, and the update-matrix stack (postorder => children are on top)
+        S.f_lptr.resize(nf);
+        S.f_uptr.resize(nf);
+        S.f_sptr.resize(nf);
+        long long fo = 0, sp = 0, peak = 0;
+        for(int s = 0; s < nf; ++s)
+        {
+            long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
+            S.f_lptr[s] = fo;
+            fo += m * p;
+            S.f_uptr[s] = fo;
+            fo += p * u;
+            for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+            {
+                long long const uc = S.f_u[S.f_child[a]];
+                sp -= uc * uc;
+            }
+            S.f_sptr[s] = sp;
+            sp += u * u;
+            peak = std::max(peak, sp);
+        }
+        // the stack discipline requires each front's children to sit contiguously on top when it runs
+        {
+            long long chk = 0;
+            for(int s = 0; s < nf; ++s)
+            {
+                long long kids = 0;
+                for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+                {
+                    long long const uc = S.f_u[S.f_child[a]];
+                    kids += uc * uc;
+                }
+                if(S.f_sptr[s] != chk - kids)
+                {
+                    S.error = "internal: update stack is not LIFO";
+                    return false;
+                }
+                chk = S.f_sptr[s] + static_cast<long long>(S.f_u[s]) * S.f_u[s];
+            }
+        }
+        S.factor_doubles = fo;
+        S.arena_doubles = peak;
+        return true;
+    }
+}  // namespace pe

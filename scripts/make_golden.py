@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* by running the REAL reference (oracle/_ref/ref_driver, built by
+`make -C oracle ref` from /root/reference/include) on decks produced by phy-engine_amd/deck.py.
+
+Runs only in the build container (the reference does not exist on the GPU box).  Output per case:
+    tests/golden/<case>.json   meta: analysis, dt, steps, gmin, snap_steps, newton_iters, fail_step, deck recipe
+    tests/golden/<case>.bin    float64 snapshots [len(snap_steps)][rows]
+    tests/golden/<case>.deck   the deck text (small cases only; meshes are re-generated from their seed)
+"""
+import concurrent.futures as cf
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("pe_deck", os.path.join(ROOT, "phy-engine_amd", "deck.py"))
+deck = importlib.util.module_from_spec(spec)
+sys.modules["pe_deck"] = deck
+spec.loader.exec_module(deck)
+
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+S4 = "1,10,100,1000"
+EVERY100 = ",".join(str(i) for i in range(100, 4001, 100))
+
+# name: (recipe (fn, kwargs), analysis, dt, steps, gmin, snaps, keep_deck)
+CASES = {
+    "rc_step": (("rc_step", {}), "TR", 1e-8, 100, 0.0, "1,50,100", True),
+    "rl_step": (("rl_step", {}), "TR", 1e-8, 100, 0.0, "1,50,100", True),
+    "rlc_series_vl": (("rlc_series_vl", {}), "TR", 1e-6, 200, 0.0, "1,100,200", True),
+    "rlc_series_vl_trop": (("rlc_series_vl", {}), "TROP", 1e-6, 50, 0.0, "0,1,50", True),
+    "divider_dc": (("divider_dc", {}), "DC", 0.0, 0, 0.0, "", True),
+    "diode_op": (("diode_op", {}), "OP", 0.0, 0, 0.0, "", True),
+    "floating_rc_dc": (("floating_rc", {}), "DC", 0.0, 0, 0.0, "", True),
+    "bridge_c2": (("bridge_rectifier", {}), "TR", 1e-5, 4000, 1e-12, EVERY100, True),
+    "bridge_gmin0_fail": (("bridge_rectifier", {}), "TR", 1e-4, 100, 0.0, "50", True),
+    "ladder_c1": (("resistor_ladder", {"n": 1000, "merges": 100, "seed": 1}), "DC", 0.0, 0, 0.0, "", False),
+    "mesh32_lin": (("rc_mesh", {"W": 32, "H": 32, "seed": 1, "nonlinear": False}), "TR", 1e-10, 1000, 0.0, S4, False),
+    "mesh32_nl": (("rc_mesh", {"W": 32, "H": 32, "seed": 1, "nonlinear": True}), "TR", 1e-10, 1000, 0.0, S4, False),
+    "mesh100_lin": (("rc_mesh", {"W": 100, "H": 100, "seed": 1, "nonlinear": False}), "TR", 1e-10, 1000, 0.0, S4, False),
+    "mesh100_nl": (("rc_mesh", {"W": 100, "H": 100, "seed": 1, "nonlinear": True}), "TR", 1e-10, 1000, 0.0, S4, False),
+}
+for sd in range(2, 9):
+    CASES[f"mesh32_lin_seed{sd}"] = (("rc_mesh", {"W": 32, "H": 32, "seed": sd, "nonlinear": False}), "TR", 1e-10, 100, 0.0, "100", False)
+    CASES[f"mesh32_nl_seed{sd}"] = (("rc_mesh", {"W": 32, "H": 32, "seed": sd, "nonlinear": True}), "TR", 1e-10, 100, 0.0, "100", False)
+CASES["mesh100_lin_seed2"] = (("rc_mesh", {"W": 100, "H": 100, "seed": 2, "nonlinear": False}), "TR", 1e-10, 100, 0.0, "100", False)
+
+
+def tt_diode_deck():
+    """test/0004.solver/pn_junction_tt_tr.cpp: VDC 0.7 + VAC 0.1 (omega*dt = pi/2) across a tt=1e-9 diode."""
+    import math
+    d = deck.Deck()
+    d.n_nodes = 2
+    d.add("VDC", (1, 0), 0.7)
+    d.add("VAC", (2, 1), 0.1, math.pi / (2.0 * 1e-8), 0.0)
+    d.add("D", (2, 0), 1e-14, 1.0, 0.0, 2.0, 27.0, 1e-3, 40.0, 1.0, 1.0, 1e-9)
+    return d
+
+
+deck.tt_diode = tt_diode_deck
+CASES["pn_tt_tr"] = (("tt_diode", {}), "TR", 1e-8, 2, 0.0, "1,2", True)
+
+
+def run_case(name):
+    (fn, kw), analysis, dt, steps, gmin, snaps, keep = CASES[name]
+    d = getattr(deck, fn)(**kw)
+    with tempfile.TemporaryDirectory() as tmp:
+        dp = os.path.join(tmp, name + ".deck")
+        d.write(dp)
+        out = os.path.join(tmp, name)
+        cmd = [DRIVER, dp, "--analysis", analysis, "--gmin", repr(gmin), "--out", out]
+        if analysis in ("TR", "TROP"):
+            cmd += ["--dt", repr(dt), "--steps", str(steps), "--snap", snaps]
+        if d.rows <= 2000:
+            cmd += ["--check-analyze"]
+        subprocess.run(cmd, check=True)
+        meta = json.load(open(out + ".json"))
+        meta["recipe"] = {"fn": fn, "kwargs": kw}
+        meta["generator"] = "scripts/make_golden.py via oracle/_ref/ref_driver (real reference)"
+        json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
+        os.replace(out + ".bin", os.path.join(GOLD, name + ".bin"))
+        if keep:
+            d.write(os.path.join(GOLD, name + ".deck"))
+    return name, meta["rows"], meta["fail_step"], meta.get("analyze_bit_equal")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(CASES)
+    os.makedirs(GOLD, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
+        for r in ex.map(run_case, names):
+            print(r, flush=True)
