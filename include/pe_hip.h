@@ -1,0 +1,161 @@
+/* pe_hip.h -- C ABI of the MI355X-native transient engine (libpe_hip.so).
+ *
+ * This is the drop-in boundary behind Phy-Engine's solver seam.  Plain pointers and sizes only; every
+ * function returns 0 on success and a negative pe_hip_status otherwise; no exception crosses the boundary;
+ * a handle is thread-compatible (one thread at a time), distinct handles are independent.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   include/phy_engine/circuits/solver/cuda_sparse_lu.h:465-473   cuda_sparse_lu::solve_csr_real(...)
+ *        -> pe_hip_solve_csr_real()             (same arguments, host pointers, caller-owned)
+ *   include/phy_engine/circuits/solver/cuda_sparse_lu.h:27-34     struct timings
+ *        -> pe_hip_timings
+ *   include/phy_engine/circuits/circuit.h:1122-1482               the CUDA branch of circult::solve_once
+ *   include/phy_engine/circuits/circuit.h:233-256,363-374,892-985 TR loop / update_tr_step / Newton loop
+ *        -> pe_hip_load_circuit() + pe_hip_analyze_tr()/pe_hip_analyze_dc(): the whole per-time-step path
+ *           (device stamps, g_min, LU, triangular solves, Newton test, trapezoidal companion update) stays
+ *           resident on the GPU; the host only reads node voltages / branch currents back.
+ *   include/phy_engine/circuits/circuit.h:63-68,115-121           cuda_solve_policy / cuda_node_threshold
+ *        -> pe_hip_device_count() is what `auto_select` consults.
+ */
+#ifndef PE_HIP_H
+#define PE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pe_hip_engine pe_hip_engine; /* opaque */
+
+enum pe_hip_status
+{
+    PE_HIP_OK = 0,
+    PE_HIP_ERR_ARG = -1,       /* bad argument / call order */
+    PE_HIP_ERR_NO_DEVICE = -2, /* no HIP device, or the HIP runtime failed */
+    PE_HIP_ERR_SINGULAR = -3,  /* zero / non-finite pivot (reference: factorizationIsOk()==false, circuit.h:1517) */
+    PE_HIP_ERR_NO_CONVERGENCE = -4, /* Newton exhausted max_iter (reference: solve() returns false, circuit.h:984) */
+    PE_HIP_ERR_INTERNAL = -5
+};
+
+/* device kinds of the resident path; parameter columns per device in `params` */
+enum pe_hip_kind
+{
+    PE_HIP_R = 1,    /* nodes a,b        params: r                           (linear/resistance.h:82-110) */
+    PE_HIP_C = 2,    /* nodes a,b        params: C                           (linear/capacitor.h:106-155) */
+    PE_HIP_L = 3,    /* nodes a,b +branch params: L                          (linear/inductor.h:134-195) */
+    PE_HIP_VDC = 4,  /* nodes a,b +branch params: V                          (linear/VDC.h:82-97) */
+    PE_HIP_VAC = 5,  /* nodes a,b +branch params: Vp, omega[rad/s], phase[rad] (linear/VAC.h:162-179) */
+    PE_HIP_IDC = 6,  /* nodes a,b        params: I                           (linear/IDC.h:84-95) */
+    PE_HIP_DIODE = 7 /* nodes a,c        params: Is,N,Isr,Nr,Temp,Ibv,Bv,Bv_set,Area,tt, tt_in_tr
+                                                                            (non-linear/PN_junction.h:296-503;
+                                                                             tt_in_tr=0 for the diodes of a
+                                                                             full_bridge_rectifier, which has no
+                                                                             iterate_tr: base.h:248-264) */
+};
+#define PE_HIP_DIODE_NPARAM 11
+
+/* analysis modes (phy_engine::analyze_type, circuits/analyze.h:7-16) */
+enum pe_hip_mode
+{
+    PE_HIP_MODE_OP = 0,
+    PE_HIP_MODE_DC = 1,
+    PE_HIP_MODE_TR = 4,
+    PE_HIP_MODE_TROP = 5
+};
+
+typedef struct pe_hip_device_table
+{
+    int kind;             /* pe_hip_kind */
+    int count;            /* devices in this table */
+    const int* nodes;     /* [count][2] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin */
+    const int* branch;    /* [count] global branch index (0-based, after digital drives) for L/VDC/VAC, else NULL */
+    const double* params; /* [batch][count][ncol] when params_batched, else [count][ncol] (shared by every instance) */
+    int params_batched;
+} pe_hip_device_table;
+
+/* Newton / environment knobs (phy_engine::environment, circuits/environment/environment.h:7-22; defaults of
+ * circuit.h:898-903 apply where a field is <= 0) */
+typedef struct pe_hip_options
+{
+    double v_abstol, v_reltol, i_abstol, i_reltol;
+    double g_min;
+    int max_newton; /* 0 -> 64 */
+    int refactor_every_solve; /* 1 (default): factor on every solve_once like the reference; 0: reuse the factors of a linear circuit while dt is unchanged */
+} pe_hip_options;
+
+/* mirrors cuda_sparse_lu::timings (cuda_sparse_lu.h:27-34) */
+typedef struct pe_hip_timings
+{
+    double h2d_ms, solve_ms, d2h_ms, solve_host_ms, total_host_ms, analyze_ms;
+} pe_hip_timings;
+
+typedef struct pe_hip_info
+{
+    int rows, n_nodes, n_branches, batch;
+    int nnz_a;
+    long long nnz_lu;        /* structural nnz(L)+nnz(U) of this engine's ordering (F of SURVEY.md 8d) */
+    long long nnz_lu_stored; /* entries held in the dense front panels (incl. relaxation zeros) */
+    int n_fronts, max_front, tree_depth, n_row_swaps;
+    double factor_flops;
+    long long bytes_per_instance; /* resident HBM bytes per circuit instance */
+    int n_r, n_c, n_l, n_v, n_i, n_d;
+    int nonlinear;
+} pe_hip_info;
+
+typedef struct pe_hip_run_stats
+{
+    long long steps;        /* accepted time points, summed over instances */
+    long long newton_iters; /* solve_once-equivalents, summed over instances */
+    double gpu_ms;          /* HIP-event time of the kernels of this call, on the engine's stream */
+    int n_launches;
+    int n_failed;           /* instances that stopped early */
+} pe_hip_run_stats;
+
+int pe_hip_device_count(void);
+int pe_hip_create(int device, pe_hip_engine** out);
+void pe_hip_destroy(pe_hip_engine* h);
+const char* pe_hip_last_error(pe_hip_engine* h); /* valid until the next call on h; h may be NULL (creation errors) */
+
+/* ---- drop-in for cuda_sparse_lu::solve_csr_real (cuda_sparse_lu.h:465-473): A x = b, CSR, sorted columns.
+ * copy_pattern != 0: (re)analyse the pattern; == 0: reuse the cached analysis (same n/nnz/pattern). */
+int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, const int* col_ind, const double* values,
+                          const double* b, double* x, int copy_pattern, pe_hip_timings* out);
+
+/* ---- resident path */
+int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch, int n_tables, const pe_hip_device_table* tables);
+int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* opt);
+int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out);
+
+/* digital_out of circult (circuit.h:102,509,1015-1022): ideal sources occupying the FIRST `count` branches.
+ * The count is fixed at load time through n_branches accounting: pass the drives before pe_hip_load_circuit(). */
+int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, const double* volt);
+
+/* overwrite one parameter column of one device for every instance (values: [batch] if batched else [1]) */
+int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const double* values, int batched);
+
+int pe_hip_reset(pe_hip_engine* h); /* circult::reset(), circuit.h:446-465: t = 0, x = 0, companion state cleared */
+
+/* one OP / DC / TROP solve (Newton inside), every instance */
+int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* stats);
+/* `nsteps` fixed-dt transient steps, every instance: update_tr_step -> t += dt -> Newton(solve_once) */
+int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats* stats);
+
+/* x = [node voltages ; branch currents], instance-major [count][rows] */
+int pe_hip_get_solution(pe_hip_engine* h, int first_instance, int count, double* x);
+int pe_hip_set_solution(pe_hip_engine* h, int first_instance, int count, const double* x);
+/* per-instance: status (pe_hip_status), accepted steps, Newton iterations, current time */
+int pe_hip_get_instance_state(pe_hip_engine* h, int first_instance, int count, int* status, long long* steps, long long* iters, double* t);
+/* iteration count of every step of instance 0 since the last reset (parity with the reference's Newton counts) */
+int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_out);
+/* last stamped MNA system of one instance (CSR, sorted columns; vals/rhs may be NULL) */
+int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind, double* vals, double* rhs);
+
+/* host-only: run the symbolic analysis on a pattern and report its statistics (no GPU needed) */
+int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const double* values, pe_hip_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PE_HIP_H */

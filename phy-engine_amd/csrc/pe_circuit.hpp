@@ -1,0 +1,62 @@
+// pe_circuit.hpp -- host-side compilation of device tables into the MNA pattern and the contribution lists the
+// stamp kernel gathers from.  This is the "pattern discovery" the reference performs implicitly by running every
+// model's iterate_* hook into btree_maps (circuits/MNA/mna.h:60-157, circuit.h:993-1003), done once here.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/pe_hip.h"
+#include "pe_device.hpp"
+
+namespace pe
+{
+    struct HostCircuit
+    {
+        int n_nodes{}, n_branches{}, n_drives{}, rows{}, batch{1};
+        // device arrays; rows are MNA rows (-1 = ground)
+        std::vector<int> r_a, r_b;
+        std::vector<int> c_a, c_b;
+        std::vector<int> l_a, l_b, l_k;
+        std::vector<int> vdc_a, vdc_b, vdc_k;
+        std::vector<int> vac_a, vac_b, vac_k;
+        std::vector<int> idc_a, idc_b;
+        std::vector<int> d_a, d_c;
+        std::vector<int> drv_node;  // MNA row of each digital drive
+        // per-instance parameters [batch][count(*cols)]
+        std::vector<double> r_g;      // conductance 1/r
+        std::vector<double> c_cap, l_ind, vdc_v, vac_par, idc_i;
+        std::vector<double> d_par;    // DP_NCOL derived columns
+        std::vector<double> d_raw;    // PE_HIP_DIODE_NPARAM raw columns (kept for pe_hip_update_param)
+        std::vector<double> drv_volt; // [n_drives]
+        // original table index -> compact index (-1 when the device has an unconnected pin and is skipped)
+        std::vector<int> map_r, map_c, map_l, map_vdc, map_vac, map_idc, map_d;
+        // dv layout
+        int dv_len{};
+        int dv_r{}, dv_cg{}, dv_ci{}, dv_lr{}, dv_lu{}, dv_vdc{}, dv_vac{}, dv_idc{}, dv_dg{}, dv_di{}, dv_drv{};
+        // MNA pattern (CSR, sorted columns) + contribution lists
+        std::vector<int> rp, ci;
+        std::vector<int> a_ptr, a_src;
+        std::vector<int> b_ptr, b_src;
+        bool nonlinear{};
+        std::string error;
+
+        int nR() const { return static_cast<int>(r_a.size()); }
+        int nC() const { return static_cast<int>(c_a.size()); }
+        int nL() const { return static_cast<int>(l_a.size()); }
+        int nVdc() const { return static_cast<int>(vdc_a.size()); }
+        int nVac() const { return static_cast<int>(vac_a.size()); }
+        int nIdc() const { return static_cast<int>(idc_a.size()); }
+        int nD() const { return static_cast<int>(d_a.size()); }
+    };
+
+    // Build from C-ABI tables.  drives: digital_out sources occupying branches [0, n_drives).
+    bool build_circuit(int n_nodes, int n_branches, int batch, int n_tables, pe_hip_device_table const* tables, int n_drives, int const* drv_node,
+                       double const* drv_volt, HostCircuit& hc);
+
+    // PN_junction prepare_foundation (PN_junction.h:296-354) for one diode: raw[PE_HIP_DIODE_NPARAM] -> der[DP_NCOL]
+    void diode_derive(double const* raw, double* der);
+
+    // Representative |values| of the A slots of instance 0 for the row matching (TR: capacitors 2C/dt, inductors
+    // 2L/dt; DC-like: open / short), diodes at their zero-bias conductance.
+    void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, std::vector<double>& avals);
+}  // namespace pe

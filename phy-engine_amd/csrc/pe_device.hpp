@@ -1,0 +1,88 @@
+// pe_device.hpp -- plain-data views shared by the host engine and the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace pe
+{
+    // dv ("device values") is the per-instance vector every matrix / RHS contribution is gathered from.
+    // Fixed slots first, then one block per device kind (offsets in DevView).
+    enum : int
+    {
+        DV_ONE = 0,   // 1.0  (incidence entries of B / C)
+        DV_GMIN = 1,  // env.g_min (circuit.h:1107-1110)
+        DV_FIXED = 2
+    };
+
+    // diode parameter columns after host-side prepare_foundation (PN_junction.h:296-354)
+    enum : int
+    {
+        DP_IS_EFF = 0,
+        DP_ISR_EFF,
+        DP_UTE,     // N * Ut
+        DP_UTER,    // Nr * Ut
+        DP_UTH,
+        DP_BV_EFF,
+        DP_BV_SET,  // 0 / 1
+        DP_TT,      // transit time used by step_changed_tr
+        DP_TT_STAMP,  // 1: iterate_tr stamps the diffusion-cap companion, 0: DC stamp only (FBR)
+        DP_NCOL
+    };
+
+    struct DevView
+    {
+        // ---- sizes
+        int rows, n_nodes, n_branches, batch;
+        int nnzA, dv_len;
+        int nR, nC, nL, nVdc, nVac, nIdc, nD, nDrv;
+        int nonlinear;
+        // ---- dv block offsets
+        int dv_r, dv_cg, dv_ci, dv_lr, dv_lu, dv_vdc, dv_vac, dv_idc, dv_dg, dv_di, dv_drv;
+        // ---- topology (shared by all instances); rows are MNA row indices, -1 = ground
+        int const *c_a, *c_b;
+        int const *l_a, *l_b, *l_k;  // l_k = absolute row of the branch
+        int const *vac_k;
+        int const *d_a, *d_c;
+        // ---- stamping: CSR of contributions per A slot / per RHS row; entry = (dv index << 1) | negate
+        int const *a_ptr, *a_src;
+        int const *b_ptr, *b_src;
+        // ---- per-instance parameters  [batch][count(*cols)]
+        double const* c_cap;
+        double const* l_ind;
+        double const* vac_par;  // [.][nVac][3] Vp, omega, phase
+        double const* d_par;    // [.][nD][DP_NCOL]
+        // ---- per-instance state
+        double *c_hist, *c_prevg;          // [.][nC]
+        double *d_udlast, *d_geq, *d_hist, *d_prevg;  // [.][nD]
+        double* dv;     // [.][dv_len]
+        double* aval;   // [.][nnzA]
+        double* rhs;    // [.][rows]
+        double* x;      // [.][rows]   node voltages ; branch currents
+        double* xprev;  // [.][rows]   previous Newton iterate
+        double* w;      // [.][rows]   permuted work vector of the triangular solves
+        double* factor; // [.][factor_doubles]
+        double* arena;  // [.][arena_doubles]  update-matrix stack
+        double* bigfront;  // [.][bigfront_doubles] scratch for fronts that do not fit in LDS (may be null)
+        double* t_now;     // [.]
+        double* last_step; // [.]
+        int* status;       // [.]  pe_hip_status
+        long long* n_steps;  // [.]
+        long long* n_iters;  // [.]
+        int* trace;          // Newton iterations per step of instance 0
+        int trace_cap;
+        int* trace_len;
+        long long factor_doubles, arena_doubles, bigfront_doubles;
+        // ---- symbolic (shared)
+        int nfronts;
+        int const *f_col0, *f_p, *f_u;
+        int const *f_rows_ptr, *f_rows;
+        int const *f_child_ptr, *f_child;
+        int const* f_rel;       // indexed through f_rows_ptr
+        int const *f_asm_ptr, *asm_slot, *asm_pos;
+        long long const *f_lptr, *f_uptr, *f_sptr;
+        int const *row_src, *col_src;
+        int lds_front_cap;      // largest m whose m*m front is kept in LDS
+        // ---- Newton
+        double v_abstol, v_reltol, i_abstol, i_reltol;
+        int max_newton;
+    };
+}  // namespace pe

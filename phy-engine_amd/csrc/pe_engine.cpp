@@ -1,0 +1,751 @@
+// pe_engine.cpp -- C ABI (include/pe_hip.h) and host orchestration of the resident transient path.
+//
+// The host side does what circult::analyze()/prepare() do around the hot loop (circuit.h:179-296, 468-890):
+// index, build the pattern once, decide how many steps to run; everything per time step runs in the kernels.
+// There is deliberately NO CPU numeric fallback here: without a HIP device every compute entry point fails
+// with PE_HIP_ERR_NO_DEVICE and a message.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pe_hip.h"
+#include "pe_circuit.hpp"
+#include "pe_device.hpp"
+#include "pe_kernels.hpp"
+#include "pe_symbolic.hpp"
+
+namespace
+{
+    using clk = std::chrono::steady_clock;
+    inline double ms_since(clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); }
+
+    thread_local std::string g_create_error;
+
+    struct Pool
+    {
+        std::vector<void*> ptrs;
+        size_t bytes{};
+        ~Pool() { release(); }
+        void release()
+        {
+            for(void* p: ptrs) (void)hipFree(p);
+            ptrs.clear();
+            bytes = 0;
+        }
+        template <class T>
+        hipError_t alloc(T*& out, size_t n, bool zero = true)
+        {
+            out = nullptr;
+            size_t const b = std::max<size_t>(n, 1) * sizeof(T);
+            void* p{};
+            hipError_t e = hipMalloc(&p, b);
+            if(e != hipSuccess) return e;
+            ptrs.push_back(p);
+            bytes += b;
+            if(zero)
+            {
+                e = hipMemset(p, 0, b);
+                if(e != hipSuccess) return e;
+            }
+            out = static_cast<T*>(p);
+            return hipSuccess;
+        }
+        template <class T>
+        hipError_t upload(T const*& out, std::vector<T> const& v)
+        {
+            T* p{};
+            hipError_t e = alloc(p, v.size(), false);
+            if(e != hipSuccess) return e;
+            if(!v.empty()) e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+            out = p;
+            return e;
+        }
+    };
+}  // namespace
+
+struct pe_hip_engine
+{
+    int device{};
+    hipStream_t stream{};
+    hipEvent_t ev0{}, ev1{};
+    std::string err;
+    pe_hip_options opt{};
+    int lds_limit{65536};
+
+    // resident circuit
+    bool loaded{};
+    pe::HostCircuit hc;
+    std::vector<int> drv_node;
+    std::vector<double> drv_volt;
+    Pool circ_pool;  // topology, params, state
+    Pool sym_pool;   // symbolic arrays + factor storage
+    pe::Symbolic sym;
+    int sym_class{-1};  // 0: static (OP/DC/TROP) pattern weights, 1: TR
+    pe::DevView V{};
+    size_t lds_bytes{};
+    bool fact_valid{};
+    double fact_dt{};
+    double analyze_ms{};
+
+    // solve_csr_real seam (separate small state)
+    struct Csr
+    {
+        Pool pool;
+        pe::Symbolic sym;
+        pe::DevView V{};
+        size_t lds_bytes{};
+        int n{-1}, nnz{-1};
+        bool have{};
+    } csr;
+};
+
+#define HIPCHK(h, expr)                                                                             \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if(e__ != hipSuccess)                                                                       \
+        {                                                                                           \
+            (h)->err = std::string("HIP error: ") + hipGetErrorString(e__) + " at " #expr;          \
+            return PE_HIP_ERR_NO_DEVICE;                                                            \
+        }                                                                                           \
+    } while(0)
+
+namespace
+{
+    int fail(pe_hip_engine* h, int code, std::string msg)
+    {
+        h->err = std::move(msg);
+        return code;
+    }
+
+    void apply_options(pe_hip_engine* h, pe::DevView& V)
+    {
+        auto const& o = h->opt;
+        V.v_abstol = o.v_abstol > 0.0 ? o.v_abstol : 1e-6;   // circuit.h:900-903
+        V.v_reltol = o.v_reltol > 0.0 ? o.v_reltol : 1e-3;
+        V.i_abstol = o.i_abstol > 0.0 ? o.i_abstol : 1e-12;
+        V.i_reltol = o.i_reltol > 0.0 ? o.i_reltol : V.v_reltol;
+        V.max_newton = o.max_newton > 0 ? o.max_newton : 64;
+    }
+
+    // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
+    int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic const& S, pe::DevView& V, int batch, size_t& lds_bytes)
+    {
+        V.nfronts = S.nfronts;
+        HIPCHK(h, pool.upload(V.f_col0, S.f_col0));
+        HIPCHK(h, pool.upload(V.f_p, S.f_p));
+        HIPCHK(h, pool.upload(V.f_u, S.f_u));
+        HIPCHK(h, pool.upload(V.f_rows_ptr, S.f_rows_ptr));
+        HIPCHK(h, pool.upload(V.f_rows, S.f_rows));
+        HIPCHK(h, pool.upload(V.f_child_ptr, S.f_child_ptr));
+        HIPCHK(h, pool.upload(V.f_child, S.f_child));
+        HIPCHK(h, pool.upload(V.f_rel, S.f_rel));
+        HIPCHK(h, pool.upload(V.f_asm_ptr, S.f_asm_ptr));
+        HIPCHK(h, pool.upload(V.asm_slot, S.asm_slot));
+        HIPCHK(h, pool.upload(V.asm_pos, S.asm_pos));
+        HIPCHK(h, pool.upload(V.f_lptr, S.f_lptr));
+        HIPCHK(h, pool.upload(V.f_uptr, S.f_uptr));
+        HIPCHK(h, pool.upload(V.f_sptr, S.f_sptr));
+        HIPCHK(h, pool.upload(V.row_src, S.row_src));
+        HIPCHK(h, pool.upload(V.col_src, S.col_src));
+        // LDS budget: front (cap^2) + yl (max_m) doubles
+        int cap = S.max_m;
+        while(cap > 1 && (static_cast<size_t>(cap) * cap + S.max_m + 2) * sizeof(double) > static_cast<size_t>(h->lds_limit)) --cap;
+        V.lds_front_cap = cap;
+        lds_bytes = pe::lds_bytes_for(V, S.max_m);
+        V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
+        V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
+        V.bigfront_doubles = (S.max_m > cap) ? static_cast<long long>(S.max_m) * S.max_m : 0;
+        HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
+        HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
+        if(V.bigfront_doubles) HIPCHK(h, pool.alloc(V.bigfront, static_cast<size_t>(V.bigfront_doubles) * batch));
+        else
+            V.bigfront = nullptr;
+        return PE_HIP_OK;
+    }
+
+    int ensure_symbolic(pe_hip_engine* h, bool tr, double dt)
+    {
+        int const cls = tr ? 1 : 0;
+        if(h->sym_class == cls) return PE_HIP_OK;
+        auto const t0 = clk::now();
+        std::vector<double> av;
+        pe::estimate_values(h->hc, tr, dt, h->opt.g_min, av);
+        pe::SymbolicOptions so{};
+        if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
+        {
+            h->sym_class = -1;
+            return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
+        }
+        h->sym_pool.release();
+        int const rc = upload_symbolic(h, h->sym_pool, h->sym, h->V, h->hc.batch, h->lds_bytes);
+        if(rc != PE_HIP_OK) return rc;
+        h->sym_class = cls;
+        h->fact_valid = false;
+        h->analyze_ms = ms_since(t0);
+        return PE_HIP_OK;
+    }
+
+    int collect_stats(pe_hip_engine* h, std::vector<long long> const& steps0, std::vector<long long> const& iters0, pe_hip_run_stats* st)
+    {
+        int const B = h->hc.batch;
+        std::vector<long long> s1(B), i1(B);
+        std::vector<int> status(B);
+        HIPCHK(h, hipMemcpy(s1.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(i1.data(), h->V.n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(status.data(), h->V.status, B * sizeof(int), hipMemcpyDeviceToHost));
+        int nfail = 0, first = 0;
+        long long ds = 0, di = 0;
+        for(int b = 0; b < B; ++b)
+        {
+            ds += s1[b] - steps0[b];
+            di += i1[b] - iters0[b];
+            if(status[b] != 0)
+            {
+                if(!nfail) first = status[b];
+                ++nfail;
+            }
+        }
+        if(st)
+        {
+            st->steps = ds;
+            st->newton_iters = di;
+            st->n_failed = nfail;
+        }
+        if(nfail)
+        {
+            h->err = (first == PE_HIP_ERR_SINGULAR ? "singular matrix (zero / non-finite pivot)" : "Newton iteration did not converge");
+            return first;
+        }
+        return PE_HIP_OK;
+    }
+
+    int snapshot_counters(pe_hip_engine* h, std::vector<long long>& s0, std::vector<long long>& i0)
+    {
+        int const B = h->hc.batch;
+        s0.resize(B);
+        i0.resize(B);
+        HIPCHK(h, hipMemcpy(s0.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(i0.data(), h->V.n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
+        return PE_HIP_OK;
+    }
+}  // namespace
+
+extern "C" {
+
+int pe_hip_device_count(void)
+{
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pe_hip_last_error(pe_hip_engine* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pe_hip_create(int device, pe_hip_engine** out)
+{
+    if(!out) return PE_HIP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if(hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    {
+        g_create_error = "no HIP device visible: the MI355X engine has no CPU fallback";
+        return PE_HIP_ERR_NO_DEVICE;
+    }
+    if(device < 0 || device >= n)
+    {
+        g_create_error = "device index out of range";
+        return PE_HIP_ERR_ARG;
+    }
+    auto h = std::make_unique<pe_hip_engine>();
+    h->device = device;
+    if(hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+       hipEventCreate(&h->ev1) != hipSuccess)
+    {
+        g_create_error = "HIP runtime initialisation failed";
+        return PE_HIP_ERR_NO_DEVICE;
+    }
+    int lds = 0;
+    if(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) h->lds_limit = lds;
+    h->opt.refactor_every_solve = 1;
+    *out = h.release();
+    return PE_HIP_OK;
+}
+
+void pe_hip_destroy(pe_hip_engine* h)
+{
+    if(!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    h->circ_pool.release();
+    h->sym_pool.release();
+    h->csr.pool.release();
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
+{
+    if(!h || !o) return PE_HIP_ERR_ARG;
+    bool const gmin_changed = o->g_min != h->opt.g_min;
+    h->opt = *o;
+    apply_options(h, h->V);
+    if(h->loaded && gmin_changed)
+    {
+        HIPCHK(h, hipSetDevice(h->device));
+        std::vector<double> col(h->hc.batch, o->g_min);
+        HIPCHK(h, hipMemcpy2D(h->V.dv + pe::DV_GMIN, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double), h->hc.batch,
+                              hipMemcpyHostToDevice));
+        h->fact_valid = false;
+    }
+    return PE_HIP_OK;
+}
+
+int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, const double* volt)
+{
+    if(!h || count < 0 || (count > 0 && (!node || !volt))) return PE_HIP_ERR_ARG;
+    if(h->loaded)
+    {
+        // after load only the voltages may change (same drives, same order)
+        if(count != h->hc.n_drives) return fail(h, PE_HIP_ERR_ARG, "digital drive set changed: reload the circuit");
+        for(int k = 0; k < count; ++k)
+            if((node[k] == 0 ? -1 : node[k] - 1) != h->hc.drv_node[k]) return fail(h, PE_HIP_ERR_ARG, "digital drive set changed: reload the circuit");
+        HIPCHK(h, hipSetDevice(h->device));
+        for(int k = 0; k < count; ++k)
+        {
+            std::vector<double> col(h->hc.batch, volt[k]);
+            HIPCHK(h, hipMemcpy2D(h->V.dv + h->hc.dv_drv + k, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double),
+                                  h->hc.batch, hipMemcpyHostToDevice));
+        }
+    }
+    h->drv_node.assign(node, node + count);
+    h->drv_volt.assign(volt, volt + count);
+    return PE_HIP_OK;
+}
+
+int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch, int n_tables, const pe_hip_device_table* tables)
+{
+    if(!h || (n_tables > 0 && !tables)) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->loaded = false;
+    h->sym_class = -1;
+    h->fact_valid = false;
+    h->circ_pool.release();
+    h->sym_pool.release();
+    if(!pe::build_circuit(n_nodes, n_branches, batch, n_tables, tables, static_cast<int>(h->drv_node.size()), h->drv_node.data(),
+                          h->drv_volt.data(), h->hc))
+        return fail(h, PE_HIP_ERR_ARG, "load_circuit: " + h->hc.error);
+    auto const& hc = h->hc;
+    pe::DevView V{};
+    V.rows = hc.rows;
+    V.n_nodes = hc.n_nodes;
+    V.n_branches = hc.n_branches;
+    V.batch = hc.batch;
+    V.nnzA = static_cast<int>(hc.ci.size());
+    V.dv_len = hc.dv_len;
+    V.nR = hc.nR(); V.nC = hc.nC(); V.nL = hc.nL(); V.nVdc = hc.nVdc(); V.nVac = hc.nVac(); V.nIdc = hc.nIdc(); V.nD = hc.nD();
+    V.nDrv = hc.n_drives;
+    V.nonlinear = hc.nonlinear ? 1 : 0;
+    V.dv_r = hc.dv_r; V.dv_cg = hc.dv_cg; V.dv_ci = hc.dv_ci; V.dv_lr = hc.dv_lr; V.dv_lu = hc.dv_lu; V.dv_vdc = hc.dv_vdc;
+    V.dv_vac = hc.dv_vac; V.dv_idc = hc.dv_idc; V.dv_dg = hc.dv_dg; V.dv_di = hc.dv_di; V.dv_drv = hc.dv_drv;
+    auto& P = h->circ_pool;
+    HIPCHK(h, P.upload(V.c_a, hc.c_a));
+    HIPCHK(h, P.upload(V.c_b, hc.c_b));
+    HIPCHK(h, P.upload(V.l_a, hc.l_a));
+    HIPCHK(h, P.upload(V.l_b, hc.l_b));
+    HIPCHK(h, P.upload(V.l_k, hc.l_k));
+    HIPCHK(h, P.upload(V.vac_k, hc.vac_k));
+    HIPCHK(h, P.upload(V.d_a, hc.d_a));
+    HIPCHK(h, P.upload(V.d_c, hc.d_c));
+    HIPCHK(h, P.upload(V.a_ptr, hc.a_ptr));
+    HIPCHK(h, P.upload(V.a_src, hc.a_src));
+    HIPCHK(h, P.upload(V.b_ptr, hc.b_ptr));
+    HIPCHK(h, P.upload(V.b_src, hc.b_src));
+    HIPCHK(h, P.upload(V.c_cap, hc.c_cap));
+    HIPCHK(h, P.upload(V.l_ind, hc.l_ind));
+    HIPCHK(h, P.upload(V.vac_par, hc.vac_par));
+    HIPCHK(h, P.upload(V.d_par, hc.d_par));
+    size_t const B = static_cast<size_t>(hc.batch);
+    HIPCHK(h, P.alloc(V.c_hist, B * hc.nC()));
+    HIPCHK(h, P.alloc(V.c_prevg, B * hc.nC()));
+    HIPCHK(h, P.alloc(V.d_udlast, B * hc.nD()));
+    HIPCHK(h, P.alloc(V.d_geq, B * hc.nD()));
+    HIPCHK(h, P.alloc(V.d_hist, B * hc.nD()));
+    HIPCHK(h, P.alloc(V.d_prevg, B * hc.nD()));
+    HIPCHK(h, P.alloc(V.aval, B * V.nnzA));
+    HIPCHK(h, P.alloc(V.rhs, B * hc.rows));
+    HIPCHK(h, P.alloc(V.x, B * hc.rows));
+    HIPCHK(h, P.alloc(V.xprev, B * hc.rows));
+    HIPCHK(h, P.alloc(V.w, B * hc.rows));
+    HIPCHK(h, P.alloc(V.t_now, B));
+    HIPCHK(h, P.alloc(V.last_step, B));
+    HIPCHK(h, P.alloc(V.status, B));
+    HIPCHK(h, P.alloc(V.n_steps, B));
+    HIPCHK(h, P.alloc(V.n_iters, B));
+    V.trace_cap = 1 << 16;
+    HIPCHK(h, P.alloc(V.trace, static_cast<size_t>(V.trace_cap)));
+    HIPCHK(h, P.alloc(V.trace_len, 1));
+    // static part of dv
+    {
+        std::vector<double> dv(B * hc.dv_len, 0.0);
+        for(size_t b = 0; b < B; ++b)
+        {
+            double* d = &dv[b * hc.dv_len];
+            d[pe::DV_ONE] = 1.0;
+            d[pe::DV_GMIN] = h->opt.g_min;
+            for(int i = 0; i < hc.nR(); ++i) d[hc.dv_r + i] = hc.r_g[b * hc.nR() + i];
+            for(int i = 0; i < hc.nVdc(); ++i) d[hc.dv_vdc + i] = hc.vdc_v[b * hc.nVdc() + i];
+            for(int i = 0; i < hc.nIdc(); ++i) d[hc.dv_idc + i] = hc.idc_i[b * hc.nIdc() + i];
+            for(int k = 0; k < hc.n_drives; ++k) d[hc.dv_drv + k] = hc.drv_volt[k];
+        }
+        double* ddv{};
+        HIPCHK(h, P.alloc(ddv, dv.size(), false));
+        HIPCHK(h, hipMemcpy(ddv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
+        V.dv = ddv;
+    }
+    apply_options(h, V);
+    h->V = V;
+    h->loaded = true;
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
+{
+    if(!h || !out || !h->loaded) return PE_HIP_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    auto const& hc = h->hc;
+    out->rows = hc.rows;
+    out->n_nodes = hc.n_nodes;
+    out->n_branches = hc.n_branches;
+    out->batch = hc.batch;
+    out->nnz_a = static_cast<int>(hc.ci.size());
+    out->n_r = hc.nR(); out->n_c = hc.nC(); out->n_l = hc.nL(); out->n_v = hc.nVdc() + hc.nVac() + hc.n_drives; out->n_i = hc.nIdc(); out->n_d = hc.nD();
+    out->nonlinear = hc.nonlinear;
+    if(h->sym_class >= 0)
+    {
+        out->nnz_lu = h->sym.nnz_LU;
+        out->nnz_lu_stored = h->sym.nnz_LU_stored;
+        out->n_fronts = h->sym.nfronts;
+        out->max_front = h->sym.max_m;
+        out->tree_depth = h->sym.tree_depth;
+        out->n_row_swaps = h->sym.n_row_swaps;
+        out->factor_flops = h->sym.flops;
+    }
+    out->bytes_per_instance = static_cast<long long>((h->circ_pool.bytes + h->sym_pool.bytes) / std::max(1, hc.batch));
+    return PE_HIP_OK;
+}
+
+int pe_hip_reset(pe_hip_engine* h)
+{
+    if(!h || !h->loaded) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    auto const& hc = h->hc;
+    size_t const B = static_cast<size_t>(hc.batch);
+    auto& V = h->V;
+    HIPCHK(h, hipMemset(V.x, 0, B * hc.rows * sizeof(double)));
+    HIPCHK(h, hipMemset(V.c_hist, 0, std::max<size_t>(1, B * hc.nC()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.c_prevg, 0, std::max<size_t>(1, B * hc.nC()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.d_udlast, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.d_geq, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.d_hist, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.d_prevg, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.t_now, 0, B * sizeof(double)));
+    HIPCHK(h, hipMemset(V.last_step, 0, B * sizeof(double)));
+    HIPCHK(h, hipMemset(V.status, 0, B * sizeof(int)));
+    HIPCHK(h, hipMemset(V.n_steps, 0, B * sizeof(long long)));
+    HIPCHK(h, hipMemset(V.n_iters, 0, B * sizeof(long long)));
+    HIPCHK(h, hipMemset(V.trace_len, 0, sizeof(int)));
+    h->fact_valid = false;
+    return PE_HIP_OK;
+}
+
+int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats* st)
+{
+    if(!h || !h->loaded || nsteps < 0 || !(dt > 0.0)) return h ? fail(h, PE_HIP_ERR_ARG, "analyze_tr: bad arguments or no circuit") : PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if(st) std::memset(st, 0, sizeof(*st));
+    if(h->hc.rows == 0 || nsteps == 0) return PE_HIP_OK;
+    int rc = ensure_symbolic(h, true, dt);
+    if(rc != PE_HIP_OK) return rc;
+    std::vector<long long> s0, i0;
+    rc = snapshot_counters(h, s0, i0);
+    if(rc != PE_HIP_OK) return rc;
+    bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve;
+    int const chunk = h->hc.rows > 2000 ? 32 : (h->hc.rows > 200 ? 256 : 2048);
+    int launches = 0;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    int done = 0;
+    while(done < nsteps)
+    {
+        bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
+        int const n = reuse || !may_reuse ? std::min(chunk, nsteps - done) : 1;  // first step factors, the rest may reuse
+        HIPCHK(h, pe::launch_tr_steps(h->stream, h->V, dt, n, reuse, h->lds_bytes));
+        ++launches;
+        done += n;
+        if(may_reuse)
+        {
+            h->fact_valid = true;
+            h->fact_dt = dt;
+        }
+    }
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    if(!may_reuse) h->fact_valid = false;
+    rc = collect_stats(h, s0, i0, st);
+    if(st)
+    {
+        st->gpu_ms = ms;
+        st->n_launches = launches;
+    }
+    return rc;
+}
+
+int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
+{
+    if(!h || !h->loaded) return PE_HIP_ERR_ARG;
+    if(mode != PE_HIP_MODE_OP && mode != PE_HIP_MODE_DC && mode != PE_HIP_MODE_TROP) return fail(h, PE_HIP_ERR_ARG, "analyze_dc: mode must be OP, DC or TROP");
+    HIPCHK(h, hipSetDevice(h->device));
+    if(st) std::memset(st, 0, sizeof(*st));
+    if(h->hc.rows == 0) return PE_HIP_OK;
+    int rc = ensure_symbolic(h, false, 0.0);
+    if(rc != PE_HIP_OK) return rc;
+    std::vector<long long> s0, i0;
+    rc = snapshot_counters(h, s0, i0);
+    if(rc != PE_HIP_OK) return rc;
+    h->fact_valid = false;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode, h->lds_bytes));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    rc = collect_stats(h, s0, i0, st);
+    if(st)
+    {
+        st->gpu_ms = ms;
+        st->n_launches = 1;
+    }
+    return rc;
+}
+
+int pe_hip_get_solution(pe_hip_engine* h, int first, int count, double* x)
+{
+    if(!h || !h->loaded || !x || first < 0 || count < 0 || first + count > h->hc.batch) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(x, h->V.x + static_cast<size_t>(first) * h->hc.rows, static_cast<size_t>(count) * h->hc.rows * sizeof(double),
+                        hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_set_solution(pe_hip_engine* h, int first, int count, const double* x)
+{
+    if(!h || !h->loaded || !x || first < 0 || count < 0 || first + count > h->hc.batch) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->V.x + static_cast<size_t>(first) * h->hc.rows, x, static_cast<size_t>(count) * h->hc.rows * sizeof(double),
+                        hipMemcpyHostToDevice));
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_instance_state(pe_hip_engine* h, int first, int count, int* status, long long* steps, long long* iters, double* t)
+{
+    if(!h || !h->loaded || first < 0 || count < 0 || first + count > h->hc.batch) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if(status) HIPCHK(h, hipMemcpy(status, h->V.status + first, count * sizeof(int), hipMemcpyDeviceToHost));
+    if(steps) HIPCHK(h, hipMemcpy(steps, h->V.n_steps + first, count * sizeof(long long), hipMemcpyDeviceToHost));
+    if(iters) HIPCHK(h, hipMemcpy(iters, h->V.n_iters + first, count * sizeof(long long), hipMemcpyDeviceToHost));
+    if(t) HIPCHK(h, hipMemcpy(t, h->V.t_now + first, count * sizeof(double), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_out)
+{
+    if(!h || !h->loaded || !n_out || capacity < 0) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int len = 0;
+    HIPCHK(h, hipMemcpy(&len, h->V.trace_len, sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = len;
+    int const n = std::min({len, capacity, h->V.trace_cap});
+    if(n > 0 && iters) HIPCHK(h, hipMemcpy(iters, h->V.trace, n * sizeof(int), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind, double* vals, double* rhs)
+{
+    if(!h || !h->loaded || instance < 0 || instance >= h->hc.batch) return PE_HIP_ERR_ARG;
+    auto const& hc = h->hc;
+    if(row_ptr) std::copy(hc.rp.begin(), hc.rp.end(), row_ptr);
+    if(col_ind) std::copy(hc.ci.begin(), hc.ci.end(), col_ind);
+    HIPCHK(h, hipSetDevice(h->device));
+    if(vals) HIPCHK(h, hipMemcpy(vals, h->V.aval + static_cast<size_t>(instance) * hc.ci.size(), hc.ci.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if(rhs) HIPCHK(h, hipMemcpy(rhs, h->V.rhs + static_cast<size_t>(instance) * hc.rows, hc.rows * sizeof(double), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const double* values, int batched)
+{
+    if(!h || !h->loaded || !values || index < 0 || column < 0) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    auto& hc = h->hc;
+    int const B = hc.batch;
+    auto val = [&](int b) { return batched ? values[b] : values[0]; };
+    auto put_strided = [&](double* dev_base, size_t stride_doubles, std::vector<double> const& col) -> hipError_t
+    { return hipMemcpy2D(dev_base, stride_doubles * sizeof(double), col.data(), sizeof(double), sizeof(double), B, hipMemcpyHostToDevice); };
+    std::vector<int> const* map = nullptr;
+    switch(kind)
+    {
+        case PE_HIP_R: map = &hc.map_r; break;
+        case PE_HIP_C: map = &hc.map_c; break;
+        case PE_HIP_L: map = &hc.map_l; break;
+        case PE_HIP_VDC: map = &hc.map_vdc; break;
+        case PE_HIP_VAC: map = &hc.map_vac; break;
+        case PE_HIP_IDC: map = &hc.map_idc; break;
+        case PE_HIP_DIODE: map = &hc.map_d; break;
+        default: return fail(h, PE_HIP_ERR_ARG, "update_param: unknown kind");
+    }
+    if(index >= static_cast<int>(map->size())) return fail(h, PE_HIP_ERR_ARG, "update_param: index out of range");
+    int const j = (*map)[index];
+    if(j < 0) return PE_HIP_OK;  // device with an unconnected pin: nothing resident
+    std::vector<double> col(B);
+    h->fact_valid = false;
+    switch(kind)
+    {
+        case PE_HIP_R:
+            if(column != 0) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.r_g[static_cast<size_t>(b) * hc.nR() + j] = 1.0 / val(b);
+            HIPCHK(h, put_strided(h->V.dv + hc.dv_r + j, hc.dv_len, col));
+            break;
+        case PE_HIP_C:
+            if(column != 0) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.c_cap[static_cast<size_t>(b) * hc.nC() + j] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.c_cap) + j, hc.nC(), col));
+            break;
+        case PE_HIP_L:
+            if(column != 0) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.l_ind[static_cast<size_t>(b) * hc.nL() + j] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.l_ind) + j, hc.nL(), col));
+            break;
+        case PE_HIP_VDC:
+            if(column != 0) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.vdc_v[static_cast<size_t>(b) * hc.nVdc() + j] = val(b);
+            HIPCHK(h, put_strided(h->V.dv + hc.dv_vdc + j, hc.dv_len, col));
+            break;
+        case PE_HIP_IDC:
+            if(column != 0) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.idc_i[static_cast<size_t>(b) * hc.nIdc() + j] = val(b);
+            HIPCHK(h, put_strided(h->V.dv + hc.dv_idc + j, hc.dv_len, col));
+            break;
+        case PE_HIP_VAC:
+            if(column > 2) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b) col[b] = hc.vac_par[(static_cast<size_t>(b) * hc.nVac() + j) * 3 + column] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.vac_par) + static_cast<size_t>(j) * 3 + column, static_cast<size_t>(hc.nVac()) * 3, col));
+            break;
+        case PE_HIP_DIODE:
+        {
+            if(column >= PE_HIP_DIODE_NPARAM) return PE_HIP_ERR_ARG;
+            for(int b = 0; b < B; ++b)
+            {
+                double* raw = &hc.d_raw[(static_cast<size_t>(b) * hc.nD() + j) * PE_HIP_DIODE_NPARAM];
+                raw[column] = val(b);
+                pe::diode_derive(raw, &hc.d_par[(static_cast<size_t>(b) * hc.nD() + j) * pe::DP_NCOL]);
+            }
+            for(int c = 0; c < pe::DP_NCOL; ++c)
+            {
+                for(int b = 0; b < B; ++b) col[b] = hc.d_par[(static_cast<size_t>(b) * hc.nD() + j) * pe::DP_NCOL + c];
+                HIPCHK(h, put_strided(const_cast<double*>(h->V.d_par) + static_cast<size_t>(j) * pe::DP_NCOL + c, static_cast<size_t>(hc.nD()) * pe::DP_NCOL, col));
+            }
+            break;
+        }
+    }
+    return PE_HIP_OK;
+}
+
+int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, const int* col_ind, const double* values, const double* b, double* x,
+                          int copy_pattern, pe_hip_timings* out)
+{
+    if(!h || n < 0 || nnz < 0 || !row_ptr || !col_ind || !values || !b || !x) return PE_HIP_ERR_ARG;
+    auto const t_total = clk::now();
+    pe_hip_timings tm{};
+    HIPCHK(h, hipSetDevice(h->device));
+    if(n == 0) return PE_HIP_OK;
+    auto& C = h->csr;
+    if(copy_pattern || !C.have || C.n != n || C.nnz != nnz)
+    {
+        auto const t0 = clk::now();
+        C.have = false;
+        C.pool.release();
+        pe::SymbolicOptions so{};
+        if(!pe::analyze(n, row_ptr, col_ind, values, so, C.sym))
+            return fail(h, C.sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "solve_csr_real: " + C.sym.error);
+        pe::DevView V{};
+        V.rows = n;
+        V.n_nodes = n;
+        V.batch = 1;
+        V.nnzA = nnz;
+        int rc = upload_symbolic(h, C.pool, C.sym, V, 1, C.lds_bytes);
+        if(rc != PE_HIP_OK) return rc;
+        HIPCHK(h, C.pool.alloc(V.aval, static_cast<size_t>(nnz)));
+        HIPCHK(h, C.pool.alloc(V.rhs, static_cast<size_t>(n)));
+        HIPCHK(h, C.pool.alloc(V.x, static_cast<size_t>(n)));
+        HIPCHK(h, C.pool.alloc(V.w, static_cast<size_t>(n)));
+        HIPCHK(h, C.pool.alloc(V.status, 1));
+        C.V = V;
+        C.n = n;
+        C.nnz = nnz;
+        C.have = true;
+        tm.analyze_ms = ms_since(t0);
+    }
+    auto t0 = clk::now();
+    HIPCHK(h, hipMemcpyAsync(C.V.aval, values, static_cast<size_t>(nnz) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(C.V.rhs, b, static_cast<size_t>(n) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    tm.h2d_ms = ms_since(t0);
+    t0 = clk::now();
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    HIPCHK(h, pe::launch_factor_solve(h->stream, C.V, true, C.lds_bytes));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    tm.solve_ms = ms;
+    tm.solve_host_ms = ms_since(t0);
+    t0 = clk::now();
+    int status = 0;
+    HIPCHK(h, hipMemcpy(&status, C.V.status, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(x, C.V.x, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost));
+    tm.d2h_ms = ms_since(t0);
+    tm.total_host_ms = ms_since(t_total);
+    if(out) *out = tm;
+    if(status != 0) return fail(h, PE_HIP_ERR_SINGULAR, "solve_csr_real: singular matrix (zero / non-finite pivot)");
+    return PE_HIP_OK;
+}
+
+int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const double* values, pe_hip_info* out)
+{
+    if(n < 0 || !row_ptr || !col_ind || !out) return PE_HIP_ERR_ARG;
+    pe::Symbolic S;
+    pe::SymbolicOptions so{};
+    std::memset(out, 0, sizeof(*out));
+    if(!pe::analyze(n, row_ptr, col_ind, values, so, S)) return S.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL;
+    out->rows = n;
+    out->nnz_a = row_ptr[n];
+    out->nnz_lu = S.nnz_LU;
+    out->nnz_lu_stored = S.nnz_LU_stored;
+    out->n_fronts = S.nfronts;
+    out->max_front = S.max_m;
+    out->tree_depth = S.tree_depth;
+    out->n_row_swaps = S.n_row_swaps;
+    out->factor_flops = S.flops;
+    out->bytes_per_instance = (S.factor_doubles + S.arena_doubles) * 8;
+    return PE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+"""Shared helpers of the parity tests: load golden fixtures (made by scripts/make_golden.py from the real
+reference), run a case through the C ABI, compare."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import pe_load  # noqa: E402
+
+pe = pe_load.load()
+GOLD = os.path.join(ROOT, "tests", "golden")
+MODES = {"OP": pe.ffi.MODE_OP, "DC": pe.ffi.MODE_DC, "TROP": pe.ffi.MODE_TROP}
+
+
+def golden(name):
+    meta = json.load(open(os.path.join(GOLD, name + ".json")))
+    x = np.fromfile(os.path.join(GOLD, name + ".bin")).reshape(-1, meta["rows"]) if meta["rows"] else np.zeros((0, 0))
+    dp = os.path.join(GOLD, name + ".deck")
+    if os.path.exists(dp):
+        deck = pe.deck.Deck.read(dp)
+    else:
+        deck = getattr(pe.deck, meta["recipe"]["fn"])(**meta["recipe"]["kwargs"])
+    return meta, x, deck
+
+
+def run_engine_case(eng, meta, deck, batch=1, overrides=None):
+    """Runs the golden's analysis; returns (snapshots [nsnap][batch][rows], newton trace of instance 0, fail_step)."""
+    eng.set_options(g_min=meta["gmin"])
+    eng.load_deck(deck, batch=batch, overrides=overrides)
+    eng.reset()
+    snaps = []
+    fail = -1
+    if meta["analysis"] in ("DC", "OP"):
+        st = eng.analyze_dc(MODES[meta["analysis"]], check=False)
+        if st["rc"] != 0:
+            fail = 0
+        snaps.append(eng.solution())
+    else:
+        done = 0
+        want = list(meta["snap_steps"])
+        if meta["analysis"] == "TROP":
+            st = eng.analyze_dc(MODES["TROP"], check=False)
+            if st["rc"] != 0:
+                fail = 0
+            if 0 in want:
+                snaps.append(eng.solution())
+                want.remove(0)
+        for s in want + ([meta["steps"]] if (not want or want[-1] != meta["steps"]) else []):
+            if fail >= 0:
+                break
+            st = eng.analyze_tr(meta["dt"], s - done, check=False)
+            done = s
+            if st["rc"] != 0:
+                fail = int(eng.state()["steps"][0]) + 1
+                break
+            if s in meta["snap_steps"]:
+                snaps.append(eng.solution())
+    return np.array(snaps), eng.newton_trace(), fail
+
+
+def max_err(a, b, atol, rtol):
+    """max over entries of |a-b| / (atol + rtol*|b|): <= 1 passes."""
+    return float(np.max(np.abs(a - b) / (atol + rtol * np.abs(b)))) if a.size else 0.0
