@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- transient hot path on the synthetic 10k-node RC mesh (BASELINE.json metric).
+
+Workload (config C3/C5 of SURVEY.md 8d): M10k-NL = 100x100 RC mesh, R 1k +-5%, C 1p +-5%, 1250 clamp diodes,
+VAC 2 V / 100 MHz through 50 ohm, dt = 1e-10 s.  Every GPU holds `--batch` independent Monte-Carlo instances
+(seed = global instance index + 1) that share one symbolic analysis; a "step" is one transient time step of every
+instance on that GPU (companion update -> Newton{device eval, MNA gather, multifrontal LU, triangular solves,
+convergence test}).  Weak scaling: per-GPU work is fixed, no data-path collective; the only collective is the
+final reduction of per-node statistics (RCCL all-reduce), outside the timed region and reported as reduce_ms.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One JSON line on rank 0.  value = instance-steps per second over all GPUs.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import pe_load  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def bytes_per_iteration(info):
+    """Algorithmic bytes of one Newton iteration, SURVEY.md 8(d), with this engine's own F = nnz(L)+nnz(U)."""
+    F = info["nnz_lu"]
+    N = info["rows"]
+    nnzA = info["nnz_a"]
+    b_stamp = 16 * info["n_r"] + 24 * info["n_c"] + 40 * info["n_l"] + 72 * info["n_d"] + 24 * info["n_v"] + 8 * nnzA + 8 * N
+    b_factor = 12 * nnzA + 20 * F
+    b_solve = 12 * F + 16 * N
+    b_newton = 24 * N
+    return {"stamp": b_stamp, "factor": b_factor, "solve": b_solve, "newton": b_newton, "iter": b_stamp + b_factor + b_solve + b_newton,
+            "companion_per_step": 40 * info["n_c"] + 48 * info["n_l"] + 24 * info["n_d"]}
+
+
+def node_statistics(x):
+    """Per-row {sum v, sum v^2, min, max} over the local instances: the payload of the final reduction."""
+    return np.stack([x.sum(axis=0), (x * x).sum(axis=0), x.min(axis=0), x.max(axis=0)])
+
+
+def reduce_statistics(local, dist=None, device=None):
+    """All-reduce the packed statistics over ranks: SUM for rows 0-1, MIN for row 2, MAX for row 3."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(local)).to(device or "cpu")
+    s = t[:2].contiguous()
+    mn = t[2].contiguous()
+    mx = t[3].contiguous()
+    dist.all_reduce(s, op=dist.ReduceOp.SUM)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    return torch.cat([s, mn[None], mx[None]]).cpu().numpy()
+
+
+def cpu_baseline(deck, dt, nonlinear, budget_steps):
+    """Reference CPU path on this host's cores: the real reference binary when it travelled with the repo
+    (oracle/_ref/ref_driver, kind 'reference'), else the numpy/scipy restatement (kind 'port').  1 core."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if os.path.exists(drv):
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            dp = os.path.join(tmp, "bench.deck")
+            deck.write(dp)
+            out = subprocess.run([drv, dp, "--bench", "--dt", repr(dt), "--steps", str(budget_steps), "--warmup", "1"], capture_output=True, text=True,
+                                 timeout=600)
+            if out.returncode == 0:
+                r = json.loads(out.stdout.strip().splitlines()[-1])
+                return {"value": r["steps_per_s"], "unit": "steps/s", "cores": 1, "kind": "reference",
+                        "newton_iters_per_s": r["newton_iters_per_s"],
+                        "sample": f"{budget_steps} TR steps of instance seed=1 (same deck), real reference binary (Eigen SparseLU, complex), 1 thread"}
+    orc = pe_load.load_oracle()
+    o = orc.Oracle(deck)
+    o.analyze_tr(dt, 1)
+    t0 = time.time()
+    n = max(2, budget_steps // 2)
+    o.analyze_tr(dt, n)
+    el = time.time() - t0
+    it = sum(o.newton_iters[1:])
+    return {"value": n / el, "unit": "steps/s", "cores": 1, "kind": "port", "newton_iters_per_s": it / el,
+            "sample": f"{n} TR steps of instance seed=1, oracle/pe_oracle.py (scipy SuperLU, refactor every solve), 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128, help="Monte-Carlo instances per GPU (1024-instance sweep / 8 GPUs)")
+    ap.add_argument("--mesh", type=int, default=100)
+    ap.add_argument("--linear", action="store_true", help="VDC-driven linear variant (no diodes)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=60)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    tdev = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        tdev = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=tdev)
+
+    pe = pe_load.load()
+    W = args.mesh
+    nonlinear = not args.linear
+    dt = 1e-10
+    B = args.batch
+    seeds = [rank * B + k + 1 for k in range(B)]
+    deck, r, c = pe.deck.rc_mesh_params(W, W, seeds, nonlinear)
+    eng = pe.ffi.Engine(device=local_rank)
+    eng.set_options(g_min=0.0)
+    eng.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
+    eng.reset()
+
+    def barrier():
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    st_w = eng.analyze_tr(dt, args.warmup) if args.warmup > 0 else None
+    info = eng.info()
+    barrier()
+    t0 = time.perf_counter()
+    st = eng.analyze_tr(dt, args.steps)  # synchronises the engine's stream before returning
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tmax = torch.tensor([el, st["gpu_ms"]], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([st["steps"], st["newton_iters"]], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        el, gpu_ms = float(tmax[0]), float(tmax[1])
+        steps_total, iters_total = float(tot[0]), float(tot[1])
+    else:
+        gpu_ms = st["gpu_ms"]
+        steps_total, iters_total = float(st["steps"]), float(st["newton_iters"])
+
+    # the one exchange step of the sweep: per-node statistics at t_end
+    t1 = time.perf_counter()
+    stats = reduce_statistics(node_statistics(eng.solution()), dist, tdev)
+    reduce_ms = (time.perf_counter() - t1) * 1e3
+
+    if rank == 0:
+        bpi = bytes_per_iteration(info)
+        # dominant kernel = k_tr_steps (the whole resident step).  Its launches of the timed region processed
+        # (local) newton_iters iterations + steps companion updates; duration from HIP events on the engine's stream.
+        local_bytes = bpi["iter"] * st["newton_iters"] + bpi["companion_per_step"] * st["steps"]
+        achieved = local_bytes / (st["gpu_ms"] * 1e-3) / 1e9
+        line = {
+            "metric": "transient steps/sec (+ Newton iters/sec), 10k-node RC mesh",
+            "value": steps_total / el,
+            "unit": "instance-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "newton_iters_per_s": iters_total / el,
+            "newton_iters_per_step": iters_total / max(1.0, steps_total),
+            "config": {"workload": f"M10k{'-NL' if nonlinear else ''}: {W}x{W} RC mesh Monte-Carlo sweep, {B} instances/GPU, dt=1e-10, "
+                                   f"{'1250 diodes + VAC 2V 100MHz' if nonlinear else 'VDC 1V'}",
+                       "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_per_gpu": B,
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "k_tr_steps", "bytes_per_newton_iter": bpi["iter"], "launches": st["n_launches"],
+                         "avg_launch_ms": st["gpu_ms"] / max(1, st["n_launches"])},
+            "reduce_ms": reduce_ms,
+            "stats_checksum": float(np.sum(stats[0])),
+            "engine": {k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)
+                line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
+                line["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

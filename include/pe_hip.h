@@ -155,6 +155,11 @@ int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind
 /* host-only: run the symbolic analysis on a pattern and report its statistics (no GPU needed) */
 int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const double* values, pe_hip_info* out);
 
+/* host-only: the assembly tree of that analysis.  Arrays of `capacity` ints; *n_fronts receives the count.
+ * pivots[s], updates[s] (front order m = pivots + updates), parent[s] (-1 = root); fronts are in postorder. */
+int pe_hip_analyze_pattern_fronts(int n, const int* row_ptr, const int* col_ind, const double* values, int capacity, int* pivots, int* updates,
+                                  int* parent, int* n_fronts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -748,4 +748,21 @@ int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const 
     return PE_HIP_OK;
 }
 
+int pe_hip_analyze_pattern_fronts(int n, const int* row_ptr, const int* col_ind, const double* values, int capacity, int* pivots, int* updates,
+                                  int* parent, int* n_fronts)
+{
+    if(n < 0 || !row_ptr || !col_ind || !n_fronts || capacity < 0) return PE_HIP_ERR_ARG;
+    pe::Symbolic S;
+    pe::SymbolicOptions so{};
+    if(!pe::analyze(n, row_ptr, col_ind, values, so, S)) return S.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL;
+    *n_fronts = S.nfronts;
+    for(int s = 0; s < S.nfronts && s < capacity; ++s)
+    {
+        if(pivots) pivots[s] = S.f_p[s];
+        if(updates) updates[s] = S.f_u[s];
+        if(parent) parent[s] = S.f_parent[s];
+    }
+    return PE_HIP_OK;
+}
+
 }  // extern "C"

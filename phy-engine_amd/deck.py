@@ -1,5 +1,5 @@
-"""pe-deck: the plain netlist description shared by the reference driver (oracle/ref_driver.cpp),
-the CPU oracle (oracle/pe_oracle.py) and the HIP engine's device tables.
+"""pe-deck: the plain netlist description (text format + in-memory form) from which the HIP engine's device
+tables are built; the test infrastructure reads the same text format.
 
 A deck is topology + per-device parameters, in *model insertion order* (the order fixes MNA row
 numbering exactly as the reference's `circult::prepare()` does, circuits/circuit.h:481-540):

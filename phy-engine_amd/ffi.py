@@ -24,6 +24,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
+    "pe_hip_analyze_pattern_fronts",
 ]
 
 
@@ -163,6 +164,26 @@ def deck_tables(deck, batch=1, overrides=None, n_drives=0):
             batched = 0
         tables.append((code[name], nodes, branch, par, batched))
     return deck.n_nodes, k, tables
+
+
+def analyze_pattern_fronts(n, row_ptr, col_ind, values=None):
+    """Host-only: (pivots, updates, parent) arrays of the assembly tree, fronts in postorder."""
+    rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+    ci = np.ascontiguousarray(col_ind, dtype=np.int32)
+    vals = None if values is None else np.ascontiguousarray(values, dtype=np.float64)
+    cap = max(1, int(n))
+    p = np.zeros(cap, dtype=np.int32)
+    u = np.zeros(cap, dtype=np.int32)
+    par = np.zeros(cap, dtype=np.int32)
+    nf = C.c_int()
+    fn = lib().pe_hip_analyze_pattern_fronts
+    fn.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                   C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rc = fn(int(n), _ip(rp), _ip(ci), None if vals is None else _dp(vals), cap, _ip(p), _ip(u), _ip(par), C.byref(nf))
+    if rc != 0:
+        raise PeHipError(rc, "analyze_pattern_fronts failed")
+    k = nf.value
+    return p[:k].copy(), u[:k].copy(), par[:k].copy()
 
 
 class Engine:

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with `-m gpu`)")
+
+
+@pytest.fixture(scope="session")
+def pe():
+    import pe_load
+    return pe_load.load()
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import pe_load
+    return pe_load.load_oracle()

@@ -1,0 +1,34 @@
+"""CPU, world_size 2, gloo: the only collective of the sweep (final per-node statistics reduction)."""
+import os
+import subprocess
+import sys
+
+from parity_common import ROOT
+
+WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, os.environ["PE_ROOT"])
+import bench
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+rng = np.random.default_rng(7)
+full = rng.standard_normal((6, 37))                       # 6 instances, 37 rows
+shard = full[rank * 3:(rank + 1) * 3]                     # contiguous instance blocks per rank
+out = bench.reduce_statistics(bench.node_statistics(shard), dist, torch.device("cpu"))
+ref = bench.node_statistics(full)
+assert np.allclose(out, ref, rtol=0, atol=1e-12), (out - ref)
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_sweep_reduction_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, PE_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29631", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

@@ -1,0 +1,143 @@
+"""CPU: host logic of the product (no compute on a GPU): the C-ABI library loads and exports every symbol the
+header declares, fails loudly without a device, and the symbolic analysis satisfies its structural invariants."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from parity_common import ROOT, golden
+
+
+def test_library_exports_every_header_symbol(pe):
+    hdr = open(os.path.join(ROOT, "include", "pe_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(pe_hip_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    lib = pe.ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/pe_hip.h but not exported by libpe_hip.so"
+    assert sorted(pe.ffi.EXPORTS) == declared
+
+
+def test_no_silent_cpu_fallback(pe):
+    """Without a HIP device the engine must refuse to exist (no CPU numeric path in the product)."""
+    if pe.ffi.lib().pe_hip_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(pe.ffi.PeHipError) as e:
+        pe.ffi.Engine()
+    assert e.value.code == pe.ffi.ERR_NO_DEVICE and "no CPU fallback" in str(e.value)
+
+
+def test_product_sources_never_touch_the_oracle():
+    bad = []
+    for base in ("phy-engine_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"pe_oracle|load_oracle|oracle/", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, f"product code references the oracle: {bad}"
+
+
+def _mesh_pattern(pe, oracle_mod, W, nonlinear=False):
+    d = pe.deck.rc_mesh(W, W, 1, nonlinear)
+    o = oracle_mod.Oracle(d)
+    o.prepare()
+    o.update_tr_step(1e-10)
+    o.t = 1e-10
+    A, _ = o.assemble("TR")
+    A = A.tocsr()
+    A.sort_indices()
+    return d, A
+
+
+@pytest.mark.parametrize("W", [8, 32, 100])
+def test_symbolic_invariants_on_mesh(pe, oracle_mod, W):
+    d, A = _mesh_pattern(pe, oracle_mod, W)
+    n = A.shape[0]
+    info = pe.ffi.analyze_pattern(n, A.indptr, A.indices, A.data)
+    p, u, par = pe.ffi.analyze_pattern_fronts(n, A.indptr, A.indices, A.data)
+    assert info["rows"] == n and info["nnz_a"] == A.nnz
+    assert p.sum() == n and np.all(p >= 1)                      # every unknown is a pivot exactly once
+    assert np.all((par == -1) | (par > np.arange(len(par))))    # postorder: parents after children
+    assert np.all(u[par == -1] == 0)                            # roots have no update rows
+    ch = par >= 0
+    assert np.all(u[ch] <= (p + u)[par[ch]])                    # a child's update rows live in its parent's front
+    assert info["nnz_lu"] >= A.nnz and info["nnz_lu_stored"] >= info["nnz_lu"] * 0.99
+    if W == 100:
+        # Eigen/COLAMD fill on this matrix is 645 757; the ND ordering must not be worse
+        assert n == 10002 and A.nnz == 49605
+        assert info["nnz_lu"] < 645757
+        assert info["n_row_swaps"] == 2                         # exactly the V-source branch row <-> its node row
+
+
+def test_symbolic_handles_zero_diagonal_chain(pe, oracle_mod):
+    """VDC in series with L: the node between them has no conductance (zero MNA diagonal, g_min = 0)."""
+    d = pe.deck.rlc_series_vl()
+    o = oracle_mod.Oracle(d)
+    o.update_tr_step(1e-6)
+    A, _ = o.assemble("TR")
+    A = A.tocsr()
+    A.sort_indices()
+    info = pe.ffi.analyze_pattern(A.shape[0], A.indptr, A.indices, A.data)
+    assert info["n_row_swaps"] >= 2
+
+
+def test_structurally_singular_is_reported(pe):
+    rp = np.array([0, 1, 2, 2], dtype=np.int32)  # third equation empty
+    ci = np.array([0, 1], dtype=np.int32)
+    with pytest.raises(pe.ffi.PeHipError) as e:
+        pe.ffi.analyze_pattern(3, rp, ci, np.ones(2))
+    assert e.value.code == pe.ffi.ERR_SINGULAR
+
+
+def test_deck_tables_follow_reference_numbering(pe):
+    """circuit.h:509-531: branches are numbered in model order after the digital drives; FBR -> four diodes."""
+    d = pe.deck.bridge_rectifier()
+    n_nodes, n_br, tables = pe.ffi.deck_tables(d, n_drives=2)
+    kinds = {t[0]: t for t in tables}
+    assert n_nodes == 3 and n_br == 3
+    assert list(kinds[pe.ffi.VAC][2]) == [2]
+    dn = kinds[pe.ffi.DIODE][1].tolist()
+    assert dn == [[1, 3], [2, 3], [0, 1], [0, 2]]               # full_bridge_rectifier.h:19-24
+    assert kinds[pe.ffi.DIODE][3][0, 10] == 0.0                 # tt_in_tr off: FBR has no iterate_tr
+
+
+def test_mesh_deck_matches_survey_counts(pe):
+    d = pe.deck.rc_mesh(100, 100, 1, True)
+    assert d.rows == 10002 and d.count("R") == 19801 and d.count("C") == 10000 and d.count("D") == 1249  # (i+j) % 8 == 0 on 0..99 x 0..99 (SURVEY.md says "1 250": off by one)
+    base, r, c = pe.deck.rc_mesh_params(100, 100, [1, 2], True)
+    rr = np.array([p[0] for k, _, p in base.devices if k == "R"])
+    assert np.array_equal(r[0], rr)                             # instance 0 of a sweep == the single-instance deck
+    d2 = pe.deck.rc_mesh(100, 100, 2, True)
+    assert np.array_equal(c[1], np.array([p[0] for k, _, p in d2.devices if k == "C"]))
+
+
+# ---- host emulation of the kernels' index logic (tests/emu: one-thread team, test infrastructure only) -------
+@pytest.fixture(scope="module")
+def emu_lib():
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.run(["make", "-C", emu], check=True, capture_output=True)
+    return os.path.join(emu, "libpe_hip_emu.so")
+
+
+@pytest.mark.parametrize("name", ["rc_step", "rlc_series_vl_trop", "diode_op", "bridge_c2", "mesh32_nl_seed2", "ladder_c1"])
+def test_front_code_indexing_under_host_emulation(emu_lib, name):
+    """Runs pe_front.hpp + pe_engine.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
+    This validates indexing/orchestration only; the parity proper is tests/test_gpu_parity.py on the MI355X."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np
+from parity_common import *
+meta, gx, deck = golden({name!r})
+eng = pe.ffi.Engine()
+snaps, trace, fail = run_engine_case(eng, meta, deck)
+assert fail == -1 and len(snaps) == len(gx)
+assert max_err(snaps[:, 0, :], gx, 1e-9, 1e-6) <= 1.0
+assert list(trace) == meta['newton_iters']
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
