@@ -152,6 +152,11 @@ int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_o
 /* last stamped MNA system of one instance (CSR, sorted columns; vals/rhs may be NULL) */
 int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind, double* vals, double* rhs);
 
+/* in-kernel phase clocks of one instance since the last reset, 100 MHz ticks:
+ * [0] device eval + MNA gather, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward wave fronts,
+ * [4] forward+backward cooperative fronts, [5] backward wave fronts, [6..7] reserved */
+int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8);
+
 /* host-only: run the symbolic analysis on a pattern and report its statistics (no GPU needed) */
 int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const double* values, pe_hip_info* out);
 

@@ -61,26 +61,34 @@ namespace pe
         double* w;      // [.][rows]   permuted work vector of the triangular solves
         double* factor; // [.][factor_doubles]
         double* arena;  // [.][arena_doubles]  update-matrix stack
-        double* bigfront;  // [.][bigfront_doubles] scratch for fronts that do not fit in LDS (may be null)
         double* t_now;     // [.]
         double* last_step; // [.]
         int* status;       // [.]  pe_hip_status
         long long* n_steps;  // [.]
         long long* n_iters;  // [.]
+        long long* prof;     // [.][8] phase clocks (100 MHz ticks): eval+stamp, factor waves, factor coop, fwd waves, fwd+bwd coop, bwd waves, newton, companion
         int* trace;          // Newton iterations per step of instance 0
         int trace_cap;
         int* trace_len;
-        long long factor_doubles, arena_doubles, bigfront_doubles;
+        long long factor_doubles, arena_doubles;
         // ---- symbolic (shared)
         int nfronts;
         int const *f_col0, *f_p, *f_u;
         int const *f_rows_ptr, *f_rows;
         int const *f_child_ptr, *f_child;
         int const* f_rel;       // indexed through f_rows_ptr
+        long long const* f_inv_off;  // per child edge (index into f_child), cooperative parents only
+        int const* f_inv;
         int const *f_asm_ptr, *asm_slot, *asm_pos;
         long long const *f_lptr, *f_uptr, *f_sptr;
         int const *row_src, *col_src;
-        int lds_front_cap;      // largest m whose m*m front is kept in LDS
+        // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts
+        int const *wave_ptr, *wave_list, *coop_list;
+        int n_coop, n_waves;
+        int wave_m, max_m, max_p;
+        int lds_slot;           // doubles of one wavefront's front slot (wave_m * wave_m)
+        int lds_sslot;          // doubles of one wavefront's solve scratch
+        int lds_doubles;        // dynamic LDS size of a launch, in doubles
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;
         int max_newton;

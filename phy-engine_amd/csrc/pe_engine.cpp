@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -88,7 +89,6 @@ struct pe_hip_engine
     pe::Symbolic sym;
     int sym_class{-1};  // 0: static (OP/DC/TROP) pattern weights, 1: TR
     pe::DevView V{};
-    size_t lds_bytes{};
     bool fact_valid{};
     double fact_dt{};
     double analyze_ms{};
@@ -99,7 +99,6 @@ struct pe_hip_engine
         Pool pool;
         pe::Symbolic sym;
         pe::DevView V{};
-        size_t lds_bytes{};
         int n{-1}, nnz{-1};
         bool have{};
     } csr;
@@ -134,7 +133,7 @@ namespace
     }
 
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
-    int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic const& S, pe::DevView& V, int batch, size_t& lds_bytes)
+    int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic const& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
     {
         V.nfronts = S.nfronts;
         HIPCHK(h, pool.upload(V.f_col0, S.f_col0));
@@ -145,6 +144,8 @@ namespace
         HIPCHK(h, pool.upload(V.f_child_ptr, S.f_child_ptr));
         HIPCHK(h, pool.upload(V.f_child, S.f_child));
         HIPCHK(h, pool.upload(V.f_rel, S.f_rel));
+        HIPCHK(h, pool.upload(V.f_inv_off, S.f_inv_off));
+        HIPCHK(h, pool.upload(V.f_inv, S.f_inv));
         HIPCHK(h, pool.upload(V.f_asm_ptr, S.f_asm_ptr));
         HIPCHK(h, pool.upload(V.asm_slot, S.asm_slot));
         HIPCHK(h, pool.upload(V.asm_pos, S.asm_pos));
@@ -153,20 +154,52 @@ namespace
         HIPCHK(h, pool.upload(V.f_sptr, S.f_sptr));
         HIPCHK(h, pool.upload(V.row_src, S.row_src));
         HIPCHK(h, pool.upload(V.col_src, S.col_src));
-        // LDS budget: front (cap^2) + yl (max_m) doubles
-        int cap = S.max_m;
-        while(cap > 1 && (static_cast<size_t>(cap) * cap + S.max_m + 2) * sizeof(double) > static_cast<size_t>(h->lds_limit)) --cap;
-        V.lds_front_cap = cap;
-        lds_bytes = pe::lds_bytes_for(V, S.max_m);
+        HIPCHK(h, pool.upload(V.wave_ptr, S.wave_ptr));
+        HIPCHK(h, pool.upload(V.wave_list, S.wave_list));
+        HIPCHK(h, pool.upload(V.coop_list, S.coop_list));
+        V.n_coop = static_cast<int>(S.coop_list.size());
+        V.n_waves = so.n_waves;
+        V.wave_m = so.wave_m;
+        V.max_m = std::max(S.max_m, 1);
+        V.max_p = so.max_pivots;
+        V.lds_slot = so.wave_m * so.wave_m;
+        V.lds_sslot = so.wave_m + so.wave_m * so.wave_p;
+        {
+            long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
+            need = std::max(need, so.panel_doubles);
+            need = std::max(need, static_cast<long long>(so.n_waves) * V.lds_sslot);
+            need = std::max(need, static_cast<long long>(V.max_m) + static_cast<long long>(V.max_p) * V.max_p + so.n_waves * 64);
+            V.lds_doubles = static_cast<int>(need + 2);
+        }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
-        V.bigfront_doubles = (S.max_m > cap) ? static_cast<long long>(S.max_m) * S.max_m : 0;
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
-        if(V.bigfront_doubles) HIPCHK(h, pool.alloc(V.bigfront, static_cast<size_t>(V.bigfront_doubles) * batch));
-        else
-            V.bigfront = nullptr;
         return PE_HIP_OK;
+    }
+
+    // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h)
+    {
+        pe::SymbolicOptions so{};
+        so.n_waves = PE_THREADS / 64;
+        // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
+        auto env_int = [](char const* name, int def)
+        {
+            char const* v = std::getenv(name);
+            return v && *v ? std::atoi(v) : def;
+        };
+        so.n_waves = std::clamp(env_int("PHY_ENGINE_HIP_WAVES", so.n_waves), 1, PE_THREADS / 64);
+        so.wave_m = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_M", so.wave_m));
+        so.wave_p = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_P", so.wave_p));
+        so.absorb_m = std::max(1, env_int("PHY_ENGINE_HIP_ABSORB_M", so.absorb_m));
+        so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
+        so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
+        long long const lds_doubles = h->lds_limit / 8 - 16;
+        while(static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
+        so.absorb_m = std::min(so.absorb_m, so.wave_m);
+        so.panel_doubles = std::min<long long>(lds_doubles, static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m);
+        return so;
     }
 
     int ensure_symbolic(pe_hip_engine* h, bool tr, double dt)
@@ -176,14 +209,14 @@ namespace
         auto const t0 = clk::now();
         std::vector<double> av;
         pe::estimate_values(h->hc, tr, dt, h->opt.g_min, av);
-        pe::SymbolicOptions so{};
+        pe::SymbolicOptions const so = symbolic_options(h);
         if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
         {
             h->sym_class = -1;
             return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
         }
         h->sym_pool.release();
-        int const rc = upload_symbolic(h, h->sym_pool, h->sym, h->V, h->hc.batch, h->lds_bytes);
+        int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
         h->sym_class = cls;
         h->fact_valid = false;
@@ -392,6 +425,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     V.trace_cap = 1 << 16;
     HIPCHK(h, P.alloc(V.trace, static_cast<size_t>(V.trace_cap)));
     HIPCHK(h, P.alloc(V.trace_len, 1));
+    HIPCHK(h, P.alloc(V.prof, B * 8));
     // static part of dv
     {
         std::vector<double> dv(B * hc.dv_len, 0.0);
@@ -462,6 +496,7 @@ int pe_hip_reset(pe_hip_engine* h)
     HIPCHK(h, hipMemset(V.n_steps, 0, B * sizeof(long long)));
     HIPCHK(h, hipMemset(V.n_iters, 0, B * sizeof(long long)));
     HIPCHK(h, hipMemset(V.trace_len, 0, sizeof(int)));
+    HIPCHK(h, hipMemset(V.prof, 0, B * 8 * sizeof(long long)));
     h->fact_valid = false;
     return PE_HIP_OK;
 }
@@ -486,7 +521,7 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     {
         bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
         int const n = reuse || !may_reuse ? std::min(chunk, nsteps - done) : 1;  // first step factors, the rest may reuse
-        HIPCHK(h, pe::launch_tr_steps(h->stream, h->V, dt, n, reuse, h->lds_bytes));
+        HIPCHK(h, pe::launch_tr_steps(h->stream, h->V, dt, n, reuse));
         ++launches;
         done += n;
         if(may_reuse)
@@ -523,7 +558,7 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     if(rc != PE_HIP_OK) return rc;
     h->fact_valid = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode, h->lds_bytes));
+    HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -682,7 +717,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
         auto const t0 = clk::now();
         C.have = false;
         C.pool.release();
-        pe::SymbolicOptions so{};
+        pe::SymbolicOptions const so = symbolic_options(h);
         if(!pe::analyze(n, row_ptr, col_ind, values, so, C.sym))
             return fail(h, C.sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "solve_csr_real: " + C.sym.error);
         pe::DevView V{};
@@ -690,7 +725,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
         V.n_nodes = n;
         V.batch = 1;
         V.nnzA = nnz;
-        int rc = upload_symbolic(h, C.pool, C.sym, V, 1, C.lds_bytes);
+        int rc = upload_symbolic(h, C.pool, C.sym, so, V, 1);
         if(rc != PE_HIP_OK) return rc;
         HIPCHK(h, C.pool.alloc(V.aval, static_cast<size_t>(nnz)));
         HIPCHK(h, C.pool.alloc(V.rhs, static_cast<size_t>(n)));
@@ -710,7 +745,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
     tm.h2d_ms = ms_since(t0);
     t0 = clk::now();
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, pe::launch_factor_solve(h->stream, C.V, true, C.lds_bytes));
+    HIPCHK(h, pe::launch_factor_solve(h->stream, C.V, true));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -762,6 +797,14 @@ int pe_hip_analyze_pattern_fronts(int n, const int* row_ptr, const int* col_ind,
         if(updates) updates[s] = S.f_u[s];
         if(parent) parent[s] = S.f_parent[s];
     }
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8)
+{
+    if(!h || !h->loaded || !ticks8 || instance < 0 || instance >= h->hc.batch) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(ticks8, h->V.prof + static_cast<size_t>(instance) * 8, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return PE_HIP_OK;
 }
 

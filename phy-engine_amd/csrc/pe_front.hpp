@@ -267,160 +267,683 @@ namespace pe
         }
     }
 
-    // ------------------------------------------------------------------------------------------------
-    // multifrontal LU: one dense front.  F is m x m column major (LDS when it fits, else global scratch).
-    // Returns false (uniformly over the team) on a zero / non-finite pivot.
-    // ------------------------------------------------------------------------------------------------
+    // ================================================================================================
+    // Multifrontal LU on the static assembly tree (pe_symbolic.cpp).
+    //
+    //   phase 1  WAVE fronts: every wavefront walks its own list of small subtrees (front order <= wave_m) with the
+    //            dense front in a private LDS slot -- no workgroup barrier at all;
+    //   phase 2  COOPERATIVE fronts: the whole workgroup, pivot panels (L: m x p, U: p x u) in LDS, per-pivot updates
+    //            restricted to the panels, then ONE register-tiled rank-p update of the Schur block that streams the
+    //            children's contributions from a global workspace and writes the update matrix once.
+    //
+    // Team interface used here: tid/size/sync/sync_or (workgroup), lanes() = wavefront width, wave_id()/n_waves(),
+    // wave_fence() = make this wavefront's LDS/global writes visible to its own later reads.
+    // ================================================================================================
+
+    PE_DEV bool bad_pivot(double piv) { return piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308); }
+
+    // exact idx / d for 0 <= idx < 2^22, 1 <= d <= 4096 (front-local index arithmetic), without an integer divide
+    PE_DEV int fdiv(int idx, float rcp) { return static_cast<int>((static_cast<float>(idx) + 0.5f) * rcp); }
+
+    // dst[0..n) = src[0..n)  (global -> LDS staging) with PE_UNROLL independent loads in flight per thread
+    template <int UN>
+    PE_DEV void stage_copy(double* dst, double const* src, int n, int t0, int T)
+    {
+        for(int base = t0; base < n; base += UN * T)
+        {
+            double r[UN];
+#pragma unroll
+            for(int q = 0; q < UN; ++q)
+            {
+                int const idx = base + q * T;
+                r[q] = idx < n ? src[idx] : 0.0;
+            }
+#pragma unroll
+            for(int q = 0; q < UN; ++q)
+            {
+                int const idx = base + q * T;
+                if(idx < n) dst[idx] = r[q];
+            }
+        }
+    }
+
+    // ---- one WAVE front, executed by ONE wavefront (lane, NL) with F (m x m, ld m) in that wave's LDS slot
     template <class Team>
-    PE_DEV bool factor_front(Team const& tm, DevView const& V, int b, int s, double* F)
+    PE_DEV bool wave_factor_front(Team const& tm, DevView const& V, int b, int s, double* F, int lane, int NL)
     {
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
         double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
         double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
         double* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
-        int const T = tm.size(), t0 = tm.tid();
-
-        for(int i = t0; i < m * m; i += T) F[i] = 0.0;
-        tm.sync();
-        for(int e = V.f_asm_ptr[s] + t0; e < V.f_asm_ptr[s + 1]; e += T)
+        for(int i = lane; i < m * m; i += NL) F[i] = 0.0;
+        tm.wave_fence();
         {
-            int const pos = V.asm_pos[e];
-            F[(pos >> 16) + (pos & 0xffff) * m] = a[V.asm_slot[e]];
+            int const e0 = V.f_asm_ptr[s], e1 = V.f_asm_ptr[s + 1];
+            for(int base = e0 + lane; base < e1; base += 2 * NL)
+            {
+                int const eb = base + NL;
+                int const pa = V.asm_pos[base], sa = V.asm_slot[base];
+                int const pb = eb < e1 ? V.asm_pos[eb] : 0, sb = eb < e1 ? V.asm_slot[eb] : 0;
+                double const va = a[sa];
+                double const vb = eb < e1 ? a[sb] : 0.0;
+                F[(pa >> 16) + (pa & 0xffff) * m] = va;
+                if(eb < e1) F[(pb >> 16) + (pb & 0xffff) * m] = vb;
+            }
         }
-        tm.sync();
+        tm.wave_fence();
         for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
         {
             int const c = V.f_child[ch];
             int const uc = V.f_u[c];
             double const* Sc = arena + V.f_sptr[c];
             int const* rel = V.f_rel + V.f_rows_ptr[c];
-            for(int idx = t0; idx < uc * uc; idx += T)
+            float const rcp = 1.0f / static_cast<float>(uc);
+            int const n = uc * uc;
+            for(int base = lane; base < n; base += 4 * NL)
             {
-                int const j = idx / uc, i = idx - j * uc;
-                F[rel[i] + rel[j] * m] += Sc[idx];
+                double v[4];
+                int d[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    int const idx = base + q * NL;
+                    bool const ok = idx < n;
+                    int const j = ok ? fdiv(idx, rcp) : 0, i = ok ? idx - j * uc : 0;
+                    d[q] = rel[i] + rel[j] * m;
+                    v[q] = ok ? Sc[idx] : 0.0;
+                }
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    if(base + q * NL < n) F[d[q]] += v[q];
             }
-            tm.sync();
+            tm.wave_fence();
         }
-        bool ok = true;
+        int const BX = NL >= 64 ? 8 : 1, BY = NL / BX;
+        int const li = lane % BX, lj = lane / BX;
         for(int k = 0; k < p; ++k)
         {
             double const piv = F[k + k * m];
-            if(piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))
-            {
-                ok = false;
-                break;  // uniform: every thread reads the same pivot
-            }
+            if(bad_pivot(piv)) return false;  // uniform over the wavefront
             double const inv = 1.0 / piv;
-            int const nr = m - k - 1;
-            for(int idx = t0; idx < nr * nr; idx += T)
+            for(int i = k + 1 + li; i < m; i += BX)
             {
-                int const jj = idx / nr, ii = idx - jj * nr;
-                int const i = k + 1 + ii, j = k + 1 + jj;
-                F[i + j * m] -= (F[i + k * m] * inv) * F[k + j * m];
+                double const lik = F[i + k * m] * inv;
+                // loads of a batch are issued together, then the stores: LDS latency is paid once per batch
+                for(int j0 = k + 1 + lj; j0 < m; j0 += 4 * BY)
+                {
+                    double f[4], ur[4];
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        int const j = j0 + q * BY;
+                        bool const in = j < m;
+                        f[q] = in ? F[i + j * m] : 0.0;
+                        ur[q] = in ? F[k + j * m] : 0.0;
+                    }
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        int const j = j0 + q * BY;
+                        if(j < m) F[i + j * m] = f[q] - lik * ur[q];
+                    }
+                }
+            }
+            tm.wave_fence();
+        }
+        double* Lp = fac + V.f_lptr[s];
+        for(int k = 0; k < p; ++k)
+        {
+            double const inv = 1.0 / F[k + k * m];
+            for(int i = lane; i < m; i += NL)
+            {
+                double const v = F[i + k * m];
+                Lp[i + k * m] = i > k ? v * inv : v;
+            }
+        }
+        double* Up = fac + V.f_uptr[s];
+        {
+            float const rcp = 1.0f / static_cast<float>(p);
+            for(int idx = lane; idx < p * u; idx += NL)
+            {
+                int const j = fdiv(idx, rcp), k = idx - j * p;
+                Up[idx] = F[k + (p + j) * m];
+            }
+        }
+        double* Ss = arena + V.f_sptr[s];
+        if(u > 0)
+        {
+            float const rcp = 1.0f / static_cast<float>(u);
+            for(int idx = lane; idx < u * u; idx += NL)
+            {
+                int const j = fdiv(idx, rcp), i = idx - j * u;
+                Ss[idx] = F[(p + i) + (p + j) * m];
+            }
+        }
+        tm.wave_fence();
+        return true;
+    }
+
+    // ---- one COOPERATIVE front, executed by the whole team; Lp (m x p, ld m) and Up (p x u, ld p) in LDS.
+    //
+    // Blocked right-looking LU of the pivot panels, block = 16 pivots:
+    //   (a0) wavefront 0 factors the 16 x 16 diagonal block in LDS (no workgroup barrier inside),
+    //   (a1) one thread per row below / per column right of the block solves against that block in registers,
+    //   (b)  the trailing panels are updated by 16x16x4 fp64 MFMA tiles (tm.tile_*: v_mfma_f64_16x16x4_f64),
+    // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
+    // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
+    template <class Team>
+    PE_DEV bool coop_factor_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    {
+        int const p = V.f_p[s], u = V.f_u[s], m = p + u;
+        double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
+        double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
+        double* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        double* Lp = lds;
+        double* Up = lds + m * p;
+        int const T = tm.size(), t0 = tm.tid();
+        long long const ck0 = tm.clock();
+        int const ch0 = V.f_child_ptr[s], ch1 = V.f_child_ptr[s + 1];
+        for(int i = t0; i < m * p + p * u; i += T) lds[i] = 0.0;
+        tm.sync();
+        for(int ch = ch0; ch < ch1; ++ch)
+        {
+            // entries of the child's update matrix that land in this front's pivot rows / columns
+            int const c = V.f_child[ch];
+            int const uc = V.f_u[c];
+            double const* Sc = arena + V.f_sptr[c];
+            int const* rel = V.f_rel + V.f_rows_ptr[c];
+            float const rcp = 1.0f / static_cast<float>(uc);
+            int const n = uc * uc;
+            for(int base = t0; base < n; base += 4 * T)
+            {
+                double v[4];
+                int d[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    int const idx = base + q * T;
+                    d[q] = -1;
+                    v[q] = 0.0;
+                    if(idx < n)
+                    {
+                        int const j = fdiv(idx, rcp), i = idx - j * uc;
+                        int const ri = rel[i], rj = rel[j];
+                        if(rj < p) d[q] = ri + rj * m;
+                        else if(ri < p)
+                            d[q] = m * p + ri + (rj - p) * p;
+                        if(d[q] >= 0) v[q] = Sc[idx];
+                    }
+                }
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    if(d[q] >= 0) lds[d[q]] += v[q];
             }
             tm.sync();
         }
-        if(!ok) return false;
-        // panels out: L (m x p, unit lower part scaled here; upper part + diagonal = U11), U12 (p x u), S (u x u)
-        double* Lp = fac + V.f_lptr[s];
-        for(int idx = t0; idx < m * p; idx += T)
+        for(int e = V.f_asm_ptr[s] + t0; e < V.f_asm_ptr[s + 1]; e += T)
         {
-            int const k = idx / m, i = idx - k * m;
-            double v = F[i + k * m];
-            if(i > k) v *= 1.0 / F[k + k * m];
-            Lp[idx] = v;
+            int const pos = V.asm_pos[e];
+            int const r = pos >> 16, c = pos & 0xffff;
+            double const v = a[V.asm_slot[e]];
+            if(c < p) Lp[r + c * m] += v;
+            else
+                Up[r + (c - p) * p] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
         }
-        double* Up = fac + V.f_uptr[s];
-        for(int idx = t0; idx < p * u; idx += T)
+        tm.sync();
+        long long const ck1 = tm.clock();
+        int const NW = tm.n_waves();
+        constexpr int NB = 8;
+        for(int k0 = 0; k0 < p; k0 += NB)
         {
-            int const j = idx / p, k = idx - j * p;
-            Up[idx] = F[k + (p + j) * m];
+            int const kb = p - k0 < NB ? p - k0 : NB;
+            // (a0) diagonal block, wavefront 0: LU of the kb x kb block in registers (tm.diag_lu8), L stored scaled
+            int bad = 0;
+            tm.for_each_wave(
+                [&](int w, int lane, int NL)
+                {
+                    if(w == 0) bad = tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
+                });
+            if(tm.sync_or(bad)) return false;
+            // (a1) rows below the block (L) and columns right of it (U): one thread each; the 8 x 8 block and the
+            // thread's own row / column sit in registers, so the dependent chain is pure ALU
+            {
+                int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
+                int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
+                int const ncols = ncolL + u;              // plus every column of the U panel
+                if(t0 < nrows + ncols || T < nrows + ncols)
+                {
+                    double Bk[NB][NB];
+#pragma unroll
+                    for(int c = 0; c < NB; ++c)
+#pragma unroll
+                        for(int r = 0; r < NB; ++r) Bk[r][c] = (r < kb && c < kb) ? Lp[(k0 + r) + (k0 + c) * m] : (r == c ? 1.0 : 0.0);
+                    for(int q = t0; q < nrows + ncols; q += T)
+                    {
+                        double x[NB];
+                        if(q < nrows)
+                        {
+                            double* row = Lp + (k0 + kb + q) + k0 * m;
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                            {
+                                double acc = x[kk];
+#pragma unroll
+                                for(int r = 0; r < NB; ++r)
+                                    if(r < kk) acc -= x[r] * Bk[r][kk];
+                                x[kk] = acc / Bk[kk][kk];
+                            }
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                                if(kk < kb) row[kk * m] = x[kk];
+                        }
+                        else
+                        {
+                            int const jc = q - nrows;
+                            double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * p + k0;
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                            {
+                                double acc = x[kk];
+#pragma unroll
+                                for(int r = 0; r < NB; ++r)
+                                    if(r < kk) acc -= Bk[kk][r] * x[r];
+                                x[kk] = acc;
+                            }
+#pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                                if(kk < kb) col[kk] = x[kk];
+                        }
+                    }
+                }
+            }
+            tm.sync();
+            // (b) trailing update of both panels, one 16 x 16 tile per wavefront at a time
+            {
+                int const r0 = k0 + kb;
+                int const trL = (m - r0 + 15) / 16, tcL = (p - r0 + 15) / 16;   // L panel: rows r0..m, cols r0..p
+                int const trU = (p - r0 + 15) / 16, tcU = (u + 15) / 16;        // U panel: rows r0..p, all columns
+                int const nL = trL * tcL, nU = trU * tcU;
+                tm.for_each_wave(
+                    [&](int w, int lane, int NL)
+                    {
+                        for(int tile = w; tile < nL + nU; tile += NW)
+                        {
+                            double* C;
+                            double const* B;
+                            int ldc, ldb, mr, nc, row0;
+                            if(tile < nL)
+                            {
+                                int const tc = tile / trL, tr = tile - tc * trL;
+                                row0 = r0 + 16 * tr;
+                                int const col0 = r0 + 16 * tc;
+                                C = Lp + row0 + col0 * m;
+                                ldc = m;
+                                B = Lp + k0 + col0 * m;
+                                ldb = m;
+                                mr = m - row0 < 16 ? m - row0 : 16;
+                                nc = p - col0 < 16 ? p - col0 : 16;
+                            }
+                            else
+                            {
+                                int const q = tile - nL;
+                                int const tc = q / trU, tr = q - tc * trU;
+                                row0 = r0 + 16 * tr;
+                                int const col0 = 16 * tc;
+                                C = Up + row0 + col0 * p;
+                                ldc = p;
+                                B = Up + k0 + col0 * p;
+                                ldb = p;
+                                mr = p - row0 < 16 ? p - row0 : 16;
+                                nc = u - col0 < 16 ? u - col0 : 16;
+                            }
+                            auto acc = tm.tile_load(C, ldc, mr, nc, lane);
+                            tm.tile_mulsub(acc, Lp + row0 + k0 * m, m, B, ldb, mr, nc, kb, lane);
+                            tm.tile_store(acc, C, ldc, mr, nc, lane);
+                        }
+                    });
+            }
+            tm.sync();
         }
-        double* Ss = arena + V.f_sptr[s];
-        for(int idx = t0; idx < u * u; idx += T)
+        if(V.prof && t0 == 0)
         {
-            int const j = idx / u, i = idx - j * u;
-            Ss[idx] = F[(p + i) + (p + j) * m];
+            V.prof[b * 8 + 6] += ck1 - ck0;
+            V.prof[b * 8 + 7] += tm.clock() - ck1;
         }
+        // Schur block: S = (children's contributions) - L21 * U12
+        if(u > 0)
+        {
+            double* Ss = arena + V.f_sptr[s];
+            int const nt = (u + 15) / 16;
+            tm.for_each_wave(
+                [&](int w, int lane, int NL)
+                {
+                    for(int tile = w; tile < nt * nt; tile += NW)
+                    {
+                        int const tj = tile / nt, ti = tile - tj * nt;
+                        int const i0 = 16 * ti, j0 = 16 * tj;
+                        int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
+                        auto acc = tm.tile_zero();
+                        for(int ch = ch0; ch < ch1; ++ch)
+                        {
+                            int const* inv = V.f_inv + V.f_inv_off[ch] + p;
+                            int const cc = V.f_child[ch];
+                            int const uc = V.f_u[cc];
+                            double const* Sc = arena + V.f_sptr[cc];
+                            tm.tile_foreach(acc, lane,
+                                            [&](int r, int c, double& v)
+                                            {
+                                                if(r < mr && c < nc)
+                                                {
+                                                    int const ci = inv[i0 + r], cj = inv[j0 + c];
+                                                    if(ci >= 0 && cj >= 0) v += Sc[ci + cj * uc];
+                                                }
+                                            });
+                        }
+                        tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * p, p, mr, nc, p, lane);
+                        tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
+                    }
+                });
+        }
+        double* Lg = fac + V.f_lptr[s];
+        for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
         tm.sync();
         return true;
     }
 
     template <class Team>
-    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds_front)
+    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds)
     {
-        double* big = V.bigfront ? V.bigfront + static_cast<long long>(b) * V.bigfront_doubles : nullptr;
-        for(int s = 0; s < V.nfronts; ++s)
+        int fail = 0;
+        long long const c0 = tm.clock();
+        tm.for_each_wave(
+            [&](int w, int lane, int NL)
+            {
+                double* F = lds + static_cast<long long>(w) * V.lds_slot;
+                for(int q = V.wave_ptr[w]; q < V.wave_ptr[w + 1]; ++q)
+                    if(!wave_factor_front(tm, V, b, V.wave_list[q], F, lane, NL))
+                    {
+                        fail = 1;
+                        break;
+                    }
+            });
+        if(tm.sync_or(fail)) return false;
+        long long const c1 = tm.clock();
+        for(int q = 0; q < V.n_coop; ++q)
+            if(!coop_factor_front(tm, V, b, V.coop_list[q], lds)) return false;
+        if(V.prof && tm.tid() == 0)
         {
-            int const m = V.f_p[s] + V.f_u[s];
-            double* F = (m <= V.lds_front_cap) ? lds_front : big;
-            if(!factor_front(tm, V, b, s, F)) return false;
+            V.prof[b * 8 + 1] += c1 - c0;
+            V.prof[b * 8 + 2] += tm.clock() - c1;
         }
         return true;
     }
 
-    // ------------------------------------------------------------------------------------------------
-    // triangular solves.  yl: team-shared scratch of at least max_m doubles.
-    // ------------------------------------------------------------------------------------------------
+    // ================================================================================================
+    // Triangular solves on the same tree.  Forward: each front adds its children's update vectors (kept in the arena
+    // slots the update matrices used during the factorisation), solves with its L11 and passes its own update vector
+    // up -- pull-based, race-free, deterministic.  Backward: each front gathers the already final unknowns of its
+    // ancestors.  w is the permuted right-hand side / solution.
+    // ================================================================================================
     template <class Team>
-    PE_DEV void solve_all(Team const& tm, DevView const& V, int b, double* yl)
+    PE_DEV void wave_forward_front(Team const& tm, DevView const& V, int b, int s, double* sc, int lane, int NL)
+    {
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
+        double const* Lg = V.factor + static_cast<long long>(b) * V.factor_doubles + V.f_lptr[s];
+        double* t = sc;              // [m]
+        double* Ls = sc + V.wave_m;  // staged L panel [m x p]
+        for(int i = lane; i < m; i += NL) t[i] = i < p ? w[c0 + i] : 0.0;
+        stage_copy<8>(Ls, Lg, m * p, lane, NL);
+        tm.wave_fence();
+        for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
+        {
+            int const c = V.f_child[ch];
+            double const* uc = arena + V.f_sptr[c];
+            int const* rel = V.f_rel + V.f_rows_ptr[c];
+            for(int i = lane; i < V.f_u[c]; i += NL) t[rel[i]] += uc[i];
+            tm.wave_fence();
+        }
+        for(int k = 0; k + 1 < p; ++k)
+        {
+            double const yk = t[k];
+            for(int i = k + 1 + lane; i < p; i += NL) t[i] -= Ls[i + k * m] * yk;
+            tm.wave_fence();
+        }
+        for(int i = lane; i < p; i += NL) w[c0 + i] = t[i];
+        double* us = arena + V.f_sptr[s];
+        for(int i = lane; i < u; i += NL)
+        {
+            double acc = t[p + i];
+            for(int k = 0; k < p; ++k) acc -= Ls[(p + i) + k * m] * t[k];
+            us[i] = acc;
+        }
+        tm.wave_fence();
+    }
+
+    template <class Team>
+    PE_DEV void wave_backward_front(Team const& tm, DevView const& V, int b, int s, double* sc, int lane, int NL)
+    {
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        double const* Lg = fac + V.f_lptr[s];
+        double const* Ug = fac + V.f_uptr[s];
+        int const* rows = V.f_rows + V.f_rows_ptr[s];
+        double* t = sc;                // [m]: t[0..p) rhs/solution, t[p..m) gathered ancestors
+        double* Us = sc + V.wave_m;    // staged [L11\U11 block (p x p, ld p) | U12 (p x u, ld p)]
+        for(int j = lane; j < u; j += NL) t[p + j] = w[rows[j]];
+        for(int i = lane; i < p; i += NL) t[i] = w[c0 + i];
+        {
+            float const rp = 1.0f / static_cast<float>(p);
+            int const n = p * p;
+            for(int base = lane; base < n; base += 4 * NL)
+            {
+                double r[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    int const idx = base + q * NL;
+                    int const k = idx < n ? fdiv(idx, rp) : 0, i = idx < n ? idx - k * p : 0;
+                    r[q] = Lg[i + k * m];
+                }
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    if(base + q * NL < n) Us[base + q * NL] = r[q];
+            }
+        }
+        stage_copy<8>(Us + p * p, Ug, p * u, lane, NL);
+        tm.wave_fence();
+        for(int k = lane; k < p; k += NL)
+        {
+            double acc = t[k];
+            for(int j = 0; j < u; ++j) acc -= Us[p * p + k + j * p] * t[p + j];
+            t[k] = acc;
+        }
+        tm.wave_fence();
+        for(int k = p - 1; k >= 0; --k)
+        {
+            double const xk = t[k] / Us[k + k * p];
+            for(int i = lane; i < k; i += NL) t[i] -= Us[i + k * p] * xk;
+            if(lane == 0) t[k] = xk;
+            tm.wave_fence();
+        }
+        for(int i = lane; i < p; i += NL) w[c0 + i] = t[i];
+        tm.wave_fence();
+    }
+
+    // out[i] (i < nrow) = init[i] - sum_k A[i + k*lda] * x[k]  (k < ncol), A in global memory, x in LDS.
+    // All T threads: thread = (row, column chunk); partial sums meet in LDS `part` (>= T doubles).
+    template <class Team>
+    PE_DEV void team_matvec_sub(Team const& tm, double const* A, int lda, int nrow, int ncol, double const* x, double* part, int t0, int T)
+    {
+        if(nrow <= 0) return;
+        int const chunks = T / nrow > 0 ? (T / nrow < ncol ? T / nrow : (ncol > 0 ? ncol : 1)) : 1;
+        float const rr = 1.0f / static_cast<float>(nrow);
+        for(int q = t0; q < chunks * nrow; q += T)
+        {
+            int const c = fdiv(q, rr), i = q - c * nrow;
+            double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+            int k = c;
+            for(; k + 3 * chunks < ncol; k += 4 * chunks)
+            {
+                double const a0 = A[i + k * lda], a1 = A[i + (k + chunks) * lda], a2 = A[i + (k + 2 * chunks) * lda], a3 = A[i + (k + 3 * chunks) * lda];
+                acc0 += a0 * x[k];
+                acc1 += a1 * x[k + chunks];
+                acc2 += a2 * x[k + 2 * chunks];
+                acc3 += a3 * x[k + 3 * chunks];
+            }
+            for(; k < ncol; k += chunks) acc0 += A[i + k * lda] * x[k];
+            part[q] = (acc0 + acc1) + (acc2 + acc3);
+        }
+        tm.sync();
+        // caller combines: out[i] = init[i] - sum_c part[c * nrow + i]
+    }
+
+    template <class Team>
+    PE_DEV void coop_forward_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    {
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        int const T = tm.size(), t0 = tm.tid(), NL = tm.lanes();
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
+        double const* Lg = V.factor + static_cast<long long>(b) * V.factor_doubles + V.f_lptr[s];
+        double* t = lds;                              // [m]
+        double* Lb = lds + V.max_m;                   // staged L11 [p x p, ld p]
+        double* part = Lb + V.max_p * V.max_p;        // [T]
+        for(int i = t0; i < m; i += T) t[i] = i < p ? w[c0 + i] : 0.0;
+        {
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * p; idx += T)
+            {
+                int const k = fdiv(idx, rp), i = idx - k * p;
+                Lb[idx] = Lg[i + k * m];
+            }
+        }
+        tm.sync();
+        for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
+        {
+            int const c = V.f_child[ch];
+            double const* uc = arena + V.f_sptr[c];
+            int const* rel = V.f_rel + V.f_rows_ptr[c];
+            for(int i = t0; i < V.f_u[c]; i += T) t[rel[i]] += uc[i];
+            tm.sync();
+        }
+        if(t0 < NL)  // wavefront 0 runs the dependent chain without workgroup barriers
+        {
+            for(int k = 0; k + 1 < p; ++k)
+            {
+                double const yk = t[k];
+                for(int i = k + 1 + t0; i < p; i += NL) t[i] -= Lb[i + k * p] * yk;
+                tm.wave_fence();
+            }
+        }
+        tm.sync();
+        for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
+        if(u > 0)
+        {
+            int const chunks = T / u > 0 ? (T / u < p ? T / u : p) : 1;
+            team_matvec_sub(tm, Lg + p, m, u, p, t, part, t0, T);
+            double* us = arena + V.f_sptr[s];
+            for(int i = t0; i < u; i += T)
+            {
+                double acc = t[p + i];
+                for(int c = 0; c < chunks; ++c) acc -= part[c * u + i];
+                us[i] = acc;
+            }
+        }
+        tm.sync();
+    }
+
+    template <class Team>
+    PE_DEV void coop_backward_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    {
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        int const T = tm.size(), t0 = tm.tid(), NL = tm.lanes();
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        double const* Lg = fac + V.f_lptr[s];
+        double const* Ug = fac + V.f_uptr[s];
+        int const* rows = V.f_rows + V.f_rows_ptr[s];
+        double* t = lds;                              // [m]
+        double* Ub = lds + V.max_m;                   // staged U11 [p x p, ld p]
+        double* part = Ub + V.max_p * V.max_p;        // [T] partial sums of U12 * x_U
+        for(int j = t0; j < u; j += T) t[p + j] = w[rows[j]];
+        for(int i = t0; i < p; i += T) t[i] = w[c0 + i];
+        {
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * p; idx += T)
+            {
+                int const k = fdiv(idx, rp), i = idx - k * p;
+                Ub[idx] = Lg[i + k * m];
+            }
+        }
+        tm.sync();
+        if(u > 0)
+        {
+            int const chunks = T / p > 0 ? (T / p < u ? T / p : u) : 1;
+            team_matvec_sub(tm, Ug, p, p, u, t + p, part, t0, T);
+            for(int k = t0; k < p; k += T)
+            {
+                double acc = t[k];
+                for(int c = 0; c < chunks; ++c) acc -= part[c * p + k];
+                t[k] = acc;
+            }
+            tm.sync();
+        }
+        if(t0 < NL)
+        {
+            for(int k = p - 1; k >= 0; --k)
+            {
+                double const xk = t[k] / Ub[k + k * p];
+                for(int i = t0; i < k; i += NL) t[i] -= Ub[i + k * p] * xk;
+                if(t0 == 0) t[k] = xk;
+                tm.wave_fence();
+            }
+        }
+        tm.sync();
+        for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
+        tm.sync();
+    }
+
+    template <class Team>
+    PE_DEV void solve_all(Team const& tm, DevView const& V, int b, double* lds)
     {
         int const T = tm.size(), t0 = tm.tid();
         double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
         double* w = V.w + static_cast<long long>(b) * V.rows;
         double* x = V.x + static_cast<long long>(b) * V.rows;
-        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
         for(int k = t0; k < V.rows; k += T) w[k] = rhs[V.row_src[k]];
         tm.sync();
-        // forward: L y = b, fronts in postorder
-        for(int s = 0; s < V.nfronts; ++s)
+        long long const c0 = tm.clock();
+        tm.for_each_wave(
+            [&](int wv, int lane, int NL)
+            {
+                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
+                for(int q = V.wave_ptr[wv]; q < V.wave_ptr[wv + 1]; ++q) wave_forward_front(tm, V, b, V.wave_list[q], sc, lane, NL);
+            });
+        tm.sync();
+        long long const c1 = tm.clock();
+        for(int q = 0; q < V.n_coop; ++q) coop_forward_front(tm, V, b, V.coop_list[q], lds);
+        for(int q = V.n_coop - 1; q >= 0; --q) coop_backward_front(tm, V, b, V.coop_list[q], lds);
+        tm.sync();
+        long long const c2 = tm.clock();
+        tm.for_each_wave(
+            [&](int wv, int lane, int NL)
+            {
+                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
+                for(int q = V.wave_ptr[wv + 1] - 1; q >= V.wave_ptr[wv]; --q) wave_backward_front(tm, V, b, V.wave_list[q], sc, lane, NL);
+            });
+        tm.sync();
+        if(V.prof && t0 == 0)
         {
-            int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-            double const* Lp = fac + V.f_lptr[s];
-            int const* rows = V.f_rows + V.f_rows_ptr[s];
-            for(int i = t0; i < p; i += T) yl[i] = w[c0 + i];
-            tm.sync();
-            for(int k = 0; k + 1 < p; ++k)
-            {
-                double const yk = yl[k];
-                for(int i = k + 1 + t0; i < p; i += T) yl[i] -= Lp[i + k * m] * yk;
-                tm.sync();
-            }
-            for(int i = t0; i < p; i += T) w[c0 + i] = yl[i];
-            for(int i = t0; i < u; i += T)
-            {
-                double acc = 0.0;
-                for(int k = 0; k < p; ++k) acc += Lp[(p + i) + k * m] * yl[k];
-                w[rows[i]] -= acc;
-            }
-            tm.sync();
-        }
-        // backward: U x = y, fronts in reverse postorder
-        for(int s = V.nfronts - 1; s >= 0; --s)
-        {
-            int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-            double const* Lp = fac + V.f_lptr[s];
-            double const* Up = fac + V.f_uptr[s];
-            int const* rows = V.f_rows + V.f_rows_ptr[s];
-            for(int j = t0; j < u; j += T) yl[p + j] = w[rows[j]];
-            tm.sync();
-            for(int k = t0; k < p; k += T)
-            {
-                double acc = w[c0 + k];
-                for(int j = 0; j < u; ++j) acc -= Up[k + j * p] * yl[p + j];
-                yl[k] = acc;
-            }
-            tm.sync();
-            for(int k = p - 1; k >= 0; --k)
-            {
-                double const xk = yl[k] / Lp[k + k * m];
-                for(int i = t0; i < k; i += T) yl[i] -= Lp[i + k * m] * xk;
-                tm.sync();
-                if(t0 == 0) yl[k] = xk;
-            }
-            tm.sync();
-            for(int k = t0; k < p; k += T) w[c0 + k] = yl[k];
-            tm.sync();
+            V.prof[b * 8 + 3] += c1 - c0;
+            V.prof[b * 8 + 4] += c2 - c1;
+            V.prof[b * 8 + 5] += tm.clock() - c2;
         }
         for(int k = t0; k < V.rows; k += T) x[V.col_src[k]] = w[k];
         tm.sync();
@@ -450,8 +973,7 @@ namespace pe
     // factorisation (same dt, same mode): stamp + triangular solves only.
     // ------------------------------------------------------------------------------------------------
     template <class Team>
-    PE_DEV int solve_point(Team const& tm, DevView const& V, int b, int mode, double t, double last_step, bool reuse_factor, double* lds_front,
-                           double* yl)
+    PE_DEV int solve_point(Team const& tm, DevView const& V, int b, int mode, double t, double last_step, bool reuse_factor, double* lds)
     {
         double* x = V.x + static_cast<long long>(b) * V.rows;
         double* xp = V.xprev + static_cast<long long>(b) * V.rows;
@@ -460,15 +982,17 @@ namespace pe
         {
             if(V.nonlinear)
                 for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
+            long long const c0 = tm.clock();
             eval_devices(tm, V, b, mode, t, last_step);
             tm.sync();
             stamp(tm, V, b);
             tm.sync();
+            if(V.prof && tm.tid() == 0) V.prof[b * 8 + 0] += tm.clock() - c0;
             if(!reuse_factor)
             {
-                if(!factor_all(tm, V, b, lds_front)) return ST_SINGULAR;
+                if(!factor_all(tm, V, b, lds)) return ST_SINGULAR;
             }
-            solve_all(tm, V, b, yl);
+            solve_all(tm, V, b, lds);
             int nonfinite = 0;
             for(int r = tm.tid(); r < V.rows; r += tm.size())
                 if(!(fabs(x[r]) <= 1.7976931348623157e308)) nonfinite = 1;
@@ -481,7 +1005,7 @@ namespace pe
 
     // TR loop of circult::analyze (circuit.h:242-254) for `nsteps` steps of one instance
     template <class Team>
-    PE_DEV void tr_steps(Team const& tm, DevView const& V, int b, double dt, int nsteps, bool reuse_factor, double* lds_front, double* yl)
+    PE_DEV void tr_steps(Team const& tm, DevView const& V, int b, double dt, int nsteps, bool reuse_factor, double* lds)
     {
         if(V.status[b] != ST_OK) return;
         double t = V.t_now[b];
@@ -493,7 +1017,7 @@ namespace pe
             tm.sync();
             double const prev = t;
             t = prev + dt;
-            int const it = solve_point(tm, V, b, MODE_TR, t, dt, reuse_factor && sidx > 0 ? true : reuse_factor, lds_front, yl);
+            int const it = solve_point(tm, V, b, MODE_TR, t, dt, reuse_factor, lds);
             if(b == 0 && tm.tid() == 0 && V.trace)
             {
                 int const pos = *V.trace_len;
@@ -522,10 +1046,10 @@ namespace pe
 
     // OP / DC / TROP point of circult::analyze (circuit.h:183-191, 257-266)
     template <class Team>
-    PE_DEV void dc_point(Team const& tm, DevView const& V, int b, int mode, double* lds_front, double* yl)
+    PE_DEV void dc_point(Team const& tm, DevView const& V, int b, int mode, double* lds)
     {
         if(V.status[b] != ST_OK) return;
-        int const it = solve_point(tm, V, b, mode, V.t_now[b], V.last_step[b], false, lds_front, yl);
+        int const it = solve_point(tm, V, b, mode, V.t_now[b], V.last_step[b], false, lds);
         tm.sync();
         if(tm.tid() == 0)
         {

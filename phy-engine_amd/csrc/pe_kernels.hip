@@ -18,9 +18,104 @@ namespace pe
         __device__ __forceinline__ int size() const { return static_cast<int>(blockDim.x); }
         __device__ __forceinline__ void sync() const { __syncthreads(); }
         __device__ __forceinline__ int sync_or(int v) const { return __syncthreads_or(v); }
+        __device__ __forceinline__ int lanes() const { return 64; }
+        __device__ __forceinline__ long long clock() const { return static_cast<long long>(wall_clock64()); }
+        // a wavefront's own LDS / global writes become visible to its own later reads (other lanes included)
+        __device__ __forceinline__ void wave_fence() const
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        template <class F>
+        __device__ __forceinline__ void for_each_wave(F&& body) const
+        {
+            body(static_cast<int>(threadIdx.x) >> 6, static_cast<int>(threadIdx.x) & 63, 64);
+        }
+        __device__ __forceinline__ int n_waves() const { return static_cast<int>(blockDim.x) >> 6; }
+
+        // LU (no pivoting) of a kb x kb block (kb <= 8) held one entry per lane: lane l <-> (row l&7, col l>>3).
+        // The dependent chain runs on cross-lane shuffles, not on LDS round trips.  On return the block in memory
+        // holds U on and above the diagonal and the SCALED multipliers below it.  Returns 1 on a bad pivot.
+        __device__ __forceinline__ int diag_lu8(double* blk, int ld, int kb, int lane) const
+        {
+            int const r = lane & 7, c = lane >> 3;
+            bool const in = r < kb && c < kb;
+            double v = in ? blk[r + c * ld] : (r == c ? 1.0 : 0.0);
+            int bad = 0;
+#pragma unroll
+            for(int kk = 0; kk < 8; ++kk)
+            {
+                double const piv = __shfl(v, kk + 8 * kk);
+                double const lrk = __shfl(v, r + 8 * kk);
+                double const ukc = __shfl(v, kk + 8 * c);
+                if(kk < kb && (piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))) bad = 1;
+                double const l = lrk / piv;
+                if(r > kk && c > kk) v -= l * ukc;
+                if(r > kk && c == kk) v = l;
+            }
+            if(in) blk[r + c * ld] = v;
+            return bad;
+        }
+
+        // ---- 16 x 16 fp64 tiles on the matrix core: v_mfma_f64_16x16x4_f64.
+        // Lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the accumulator register r of lane l is
+        // D[row = (l>>4) + 4r][col = l&15]  (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").
+        using v4d = __attribute__((ext_vector_type(4))) double;
+        struct Acc
+        {
+            v4d v;
+        };
+        __device__ __forceinline__ Acc tile_zero() const { return Acc{v4d{0.0, 0.0, 0.0, 0.0}}; }
+        __device__ __forceinline__ Acc tile_load(double const* C, int ldc, int mr, int nc, int lane) const
+        {
+            Acc a;
+            int const col = lane & 15, rb = lane >> 4;
+#pragma unroll
+            for(int r = 0; r < 4; ++r)
+            {
+                int const row = rb + 4 * r;
+                a.v[r] = (row < mr && col < nc) ? C[row + col * ldc] : 0.0;
+            }
+            return a;
+        }
+        __device__ __forceinline__ void tile_store(Acc const& a, double* C, int ldc, int mr, int nc, int lane) const
+        {
+            int const col = lane & 15, rb = lane >> 4;
+#pragma unroll
+            for(int r = 0; r < 4; ++r)
+            {
+                int const row = rb + 4 * r;
+                if(row < mr && col < nc) C[row + col * ldc] = a.v[r];
+            }
+        }
+        // acc -= A(mr x kd, ld lda) * B(kd x nc, ld ldb)
+        __device__ __forceinline__ void tile_mulsub(Acc& a, double const* A, int lda, double const* B, int ldb, int mr, int nc, int kd, int lane) const
+        {
+            int const ij = lane & 15, kq = lane >> 4;
+            for(int kk = 0; kk < kd; kk += 4)
+            {
+                int const k = kk + kq;
+                double const av = (k < kd && ij < mr) ? -A[ij + k * lda] : 0.0;
+                double const bv = (k < kd && ij < nc) ? B[k + ij * ldb] : 0.0;
+                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a.v, 0, 0, 0);
+            }
+        }
+        template <class F>
+        __device__ __forceinline__ void tile_foreach(Acc& a, int lane, F&& f) const
+        {
+            int const col = lane & 15, rb = lane >> 4;
+#pragma unroll
+            for(int r = 0; r < 4; ++r)
+            {
+                double t = a.v[r];
+                f(rb + 4 * r, col, t);
+                a.v[r] = t;
+            }
+        }
     };
 
-    // dynamic LDS: [front: cap*cap doubles][yl: max_m doubles]
+    // dynamic LDS: V.lds_doubles doubles, carved per phase by pe_front.hpp
     extern __shared__ __attribute__((aligned(16))) double pe_lds[];
 
     __global__ void __launch_bounds__(PE_THREADS) k_tr_steps(DevView V, double dt, int nsteps, int reuse_factor)
@@ -28,9 +123,7 @@ namespace pe
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
         HipTeam tm;
-        double* front = pe_lds;
-        double* yl = pe_lds + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap;
-        tr_steps(tm, V, b, dt, nsteps, reuse_factor != 0, front, yl);
+        tr_steps(tm, V, b, dt, nsteps, reuse_factor != 0, pe_lds);
     }
 
     __global__ void __launch_bounds__(PE_THREADS) k_dc_point(DevView V, int mode)
@@ -38,9 +131,7 @@ namespace pe
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
         HipTeam tm;
-        double* front = pe_lds;
-        double* yl = pe_lds + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap;
-        dc_point(tm, V, b, mode, front, yl);
+        dc_point(tm, V, b, mode, pe_lds);
     }
 
     // A x = b with A values / rhs already resident (solve_csr_real seam): factor + solve, instance 0..batch-1
@@ -49,13 +140,11 @@ namespace pe
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
         HipTeam tm;
-        double* front = pe_lds;
-        double* yl = pe_lds + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap;
         int st = ST_OK;
-        if(do_factor && !factor_all(tm, V, b, front)) st = ST_SINGULAR;
+        if(do_factor && !factor_all(tm, V, b, pe_lds)) st = ST_SINGULAR;
         if(st == ST_OK)
         {
-            solve_all(tm, V, b, yl);
+            solve_all(tm, V, b, pe_lds);
             double const* x = V.x + static_cast<long long>(b) * V.rows;
             int nonfinite = 0;
             for(int r = tm.tid(); r < V.rows; r += tm.size())
@@ -70,29 +159,30 @@ namespace pe
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     }
 
-    size_t lds_bytes_for(DevView const& V, int max_m) { return (static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap + static_cast<size_t>(max_m) + 2) * sizeof(double); }
-
-    hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse, size_t lds)
+    hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse)
     {
+        size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         hipError_t e = set_lds(reinterpret_cast<void const*>(&k_tr_steps), lds);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_tr_steps, dim3(V.batch), dim3(PE_THREADS), lds, st, V, dt, nsteps, reuse ? 1 : 0);
+        hipLaunchKernelGGL(k_tr_steps, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, dt, nsteps, reuse ? 1 : 0);
         return hipGetLastError();
     }
 
-    hipError_t launch_dc_point(hipStream_t st, DevView const& V, int mode, size_t lds)
+    hipError_t launch_dc_point(hipStream_t st, DevView const& V, int mode)
     {
+        size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         hipError_t e = set_lds(reinterpret_cast<void const*>(&k_dc_point), lds);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dc_point, dim3(V.batch), dim3(PE_THREADS), lds, st, V, mode);
+        hipLaunchKernelGGL(k_dc_point, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, mode);
         return hipGetLastError();
     }
 
-    hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor, size_t lds)
+    hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor)
     {
+        size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         hipError_t e = set_lds(reinterpret_cast<void const*>(&k_factor_solve), lds);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_factor_solve, dim3(V.batch), dim3(PE_THREADS), lds, st, V, do_factor ? 1 : 0);
+        hipLaunchKernelGGL(k_factor_solve, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, do_factor ? 1 : 0);
         return hipGetLastError();
     }
 }  // namespace pe

@@ -395,57 +395,62 @@ namespace pe
             return false;
         }
 
-        // two passes: (a) etree + structures in ordering q, (b) postorder with the heaviest child last, redo
+        // ---------------- elimination tree + column structures of an ordering (optionally re-postordered)
         std::vector<ivec> st;
         ivec parent;
-        for(int pass = 0; pass < 2; ++pass)
+        auto compute_tree = [&](ivec& ord, bool repostorder)
         {
-            ivec qinv(n);
-            for(int k = 0; k < n; ++k) qinv[q[k]] = k;
-            std::vector<ivec> lower(n), upper(n);
-            for(int k = 0; k < n; ++k)
+            for(int pass = 0; pass < 2; ++pass)
             {
-                int const v = q[k];
-                for(int e = gp[v]; e < gp[v + 1]; ++e)
+                ivec qinv(n);
+                for(int k = 0; k < n; ++k) qinv[ord[k]] = k;
+                std::vector<ivec> lower(n), upper(n);
+                for(int k = 0; k < n; ++k)
                 {
-                    int const l = qinv[gi[e]];
-                    if(l < k) lower[k].push_back(l);
-                    else upper[k].push_back(l);
-                }
-                std::sort(upper[k].begin(), upper[k].end());
-            }
-            etree_of(n, lower, parent);
-            col_structs(n, upper, parent, st);
-            if(pass == 1) break;
-            // postorder, children sorted by structure size ascending (largest last => mergeable with the parent)
-            std::vector<ivec> kids(n);
-            ivec roots;
-            for(int j = 0; j < n; ++j) (parent[j] >= 0 ? kids[parent[j]] : roots).push_back(j);
-            auto by_size = [&](int a, int b) { return st[a].size() != st[b].size() ? st[a].size() < st[b].size() : a < b; };
-            for(auto& kv: kids) std::sort(kv.begin(), kv.end(), by_size);
-            ivec post;
-            post.reserve(n);
-            ivec stack, itx(n, 0);
-            for(int r: roots)
-            {
-                stack.push_back(r);
-                while(!stack.empty())
-                {
-                    int const v = stack.back();
-                    if(itx[v] < static_cast<int>(kids[v].size())) stack.push_back(kids[v][itx[v]++]);
-                    else
+                    int const v = ord[k];
+                    for(int e = gp[v]; e < gp[v + 1]; ++e)
                     {
-                        post.push_back(v);
-                        stack.pop_back();
+                        int const l = qinv[gi[e]];
+                        if(l < k) lower[k].push_back(l);
+                        else upper[k].push_back(l);
+                    }
+                    std::sort(upper[k].begin(), upper[k].end());
+                }
+                etree_of(n, lower, parent);
+                col_structs(n, upper, parent, st);
+                if(pass == 1 || !repostorder) break;
+                // postorder, children sorted by structure size ascending (largest last => mergeable with the parent)
+                std::vector<ivec> kids(n);
+                ivec roots;
+                for(int j = 0; j < n; ++j) (parent[j] >= 0 ? kids[parent[j]] : roots).push_back(j);
+                auto by_size = [&](int a, int b) { return st[a].size() != st[b].size() ? st[a].size() < st[b].size() : a < b; };
+                for(auto& kv: kids) std::sort(kv.begin(), kv.end(), by_size);
+                ivec post;
+                post.reserve(n);
+                ivec stack, itx(n, 0);
+                for(int r: roots)
+                {
+                    stack.push_back(r);
+                    while(!stack.empty())
+                    {
+                        int const v = stack.back();
+                        if(itx[v] < static_cast<int>(kids[v].size())) stack.push_back(kids[v][itx[v]++]);
+                        else
+                        {
+                            post.push_back(v);
+                            stack.pop_back();
+                        }
                     }
                 }
+                ivec q2(n);
+                for(int k = 0; k < n; ++k) q2[k] = ord[post[k]];
+                ord.swap(q2);
             }
-            ivec q2(n);
-            for(int k = 0; k < n; ++k) q2[k] = q[post[k]];
-            q.swap(q2);
-        }
+        };
+        compute_tree(q, true);
+        for(int j = 0; j < n; ++j) S.nnz_LU += 2LL * static_cast<long long>(st[j].size()) + 1;
 
-        // ---------------- supernodes: fundamental runs, split at max_pivots, then relaxed merging of last children
+        // ---------------- supernodes: fundamental runs, then relaxed merging of last children
         struct SN
         {
             int c0, c1;         // columns [c0, c1)
@@ -485,8 +490,130 @@ namespace pe
             }
         }
 
-        // ---------------- fronts
-        int const nf = static_cast<int>(sn.size());
+        // ---------------- generalised absorption: a parent swallows ANY of its children while the merged front stays
+        // small enough for one wavefront (m <= absorb_m).  The absorbed columns are treated as dense (explicit zeros),
+        // which removes the tiny fronts whose cost on a GPU is pure latency.  Needs a re-permutation so that the
+        // merged columns are contiguous; fill is unchanged (same elimination tree order within every subtree).
+        std::vector<std::pair<int, int>> groups;  // forced partition [c0, c1) in the NEW order
+        {
+            int const ns = static_cast<int>(sn.size());
+            ivec col2sn(n);
+            for(int i = 0; i < ns; ++i)
+                for(int c = sn[i].c0; c < sn[i].c1; ++c) col2sn[c] = i;
+            ivec par(ns, -1), gp_(ns), gu(ns);
+            std::vector<ivec> kids(ns), members(ns);
+            for(int i = 0; i < ns; ++i)
+            {
+                auto const& r = st[sn[i].c1 - 1];
+                if(!r.empty()) par[i] = col2sn[r[0]];
+                gp_[i] = sn[i].c1 - sn[i].c0;
+                gu[i] = static_cast<int>(r.size());
+                members[i] = {i};
+            }
+            for(int i = 0; i < ns; ++i)
+                if(par[i] >= 0) kids[par[i]].push_back(i);
+            std::vector<char> absorbed(ns, 0);
+            for(int P = 0; P < ns; ++P)
+            {
+                bool again = true;
+                while(again)
+                {
+                    again = false;
+                    ivec cand = kids[P];
+                    std::sort(cand.begin(), cand.end(), [&](int a, int b) { return gp_[a] != gp_[b] ? gp_[a] < gp_[b] : a < b; });
+                    for(int C: cand)
+                    {
+                        if(gp_[P] + gp_[C] + gu[P] > opt.absorb_m || gp_[P] + gp_[C] > opt.wave_p) continue;
+                        absorbed[C] = 1;
+                        gp_[P] += gp_[C];
+                        members[P].insert(members[P].end(), members[C].begin(), members[C].end());
+                        auto& kp = kids[P];
+                        kp.erase(std::find(kp.begin(), kp.end(), C));
+                        for(int g: kids[C])
+                        {
+                            kp.push_back(g);
+                            par[g] = P;
+                        }
+                        kids[C].clear();
+                        again = true;  // grandchildren may now fit as well
+                        break;
+                    }
+                }
+            }
+            // new column order: postorder DFS of the merged tree; a node emits its member supernodes in ascending order
+            ivec q2;
+            q2.reserve(n);
+            ivec stack, itx(ns, 0);
+            for(int r = 0; r < ns; ++r)
+            {
+                if(par[r] >= 0 || absorbed[r]) continue;
+                stack.push_back(r);
+                while(!stack.empty())
+                {
+                    int const v = stack.back();
+                    if(itx[v] == 0) std::sort(kids[v].begin(), kids[v].end());
+                    if(itx[v] < static_cast<int>(kids[v].size())) stack.push_back(kids[v][itx[v]++]);
+                    else
+                    {
+                        std::sort(members[v].begin(), members[v].end());
+                        int const c0 = static_cast<int>(q2.size());
+                        for(int mbr: members[v])
+                            for(int c = sn[mbr].c0; c < sn[mbr].c1; ++c) q2.push_back(q[c]);
+                        groups.push_back({c0, static_cast<int>(q2.size())});
+                        stack.pop_back();
+                    }
+                }
+            }
+            if(static_cast<int>(q2.size()) != n)
+            {
+                S.error = "internal: absorption lost columns";
+                return false;
+            }
+            q.swap(q2);
+        }
+        compute_tree(q, false);
+
+        // ---------------- fronts = forced groups, split to respect the wave / LDS-panel limits
+        struct FR
+        {
+            int c0, c1, g1;  // pivots [c0, c1); the group ends at g1 (rows = [c1, g1) + structure of column g1-1)
+        };
+        std::vector<FR> fr;
+        for(auto const& [c0, c1]: groups)
+        {
+            int const ug = static_cast<int>(st[c1 - 1].size());
+            int a = c0;
+            while(a < c1)
+            {
+                int const rest = c1 - a;
+                int const mfull = rest + ug;
+                int b;
+                if(mfull <= opt.wave_m) b = a + std::min(rest, opt.wave_p);
+                else
+                {
+                    int pbest = 0;
+                    for(int pp = std::min(rest, opt.max_pivots); pp >= 1; --pp)
+                    {
+                        long long const uch = (rest - pp) + ug, mch = pp + uch;
+                        if(static_cast<long long>(pp) * (mch + uch) <= opt.panel_doubles)
+                        {
+                            pbest = pp;
+                            break;
+                        }
+                    }
+                    if(pbest == 0)
+                    {
+                        S.error = "front too large for the LDS panels";
+                        return false;
+                    }
+                    b = a + pbest;
+                }
+                fr.push_back({a, b, c1});
+                a = b;
+            }
+        }
+
+        int const nf = static_cast<int>(fr.size());
         S.nfronts = nf;
         S.f_col0.resize(nf);
         S.f_p.resize(nf);
@@ -496,19 +623,21 @@ namespace pe
         ivec col2front(n);
         for(int s = 0; s < nf; ++s)
         {
-            S.f_col0[s] = sn[s].c0;
-            S.f_p[s] = sn[s].c1 - sn[s].c0;
-            S.f_u[s] = u_of(sn[s]);
+            S.f_col0[s] = fr[s].c0;
+            S.f_p[s] = fr[s].c1 - fr[s].c0;
+            S.f_u[s] = (fr[s].g1 - fr[s].c1) + static_cast<int>(st[fr[s].g1 - 1].size());
             S.f_rows_ptr[s + 1] = S.f_rows_ptr[s] + S.f_u[s];
-            for(int c = sn[s].c0; c < sn[s].c1; ++c) col2front[c] = s;
+            for(int c = fr[s].c0; c < fr[s].c1; ++c) col2front[c] = s;
             S.nnz_LU_stored += 2LL * S.f_p[s] * S.f_u[s] + static_cast<long long>(S.f_p[s]) * S.f_p[s];
         }
         S.f_rows.resize(S.f_rows_ptr[nf]);
         for(int s = 0; s < nf; ++s)
         {
-            auto const& r = st[sn[s].c1 - 1];
-            std::copy(r.begin(), r.end(), S.f_rows.begin() + S.f_rows_ptr[s]);
-            if(!r.empty()) S.f_parent[s] = col2front[r[0]];
+            int* dst = S.f_rows.data() + S.f_rows_ptr[s];
+            for(int c = fr[s].c1; c < fr[s].g1; ++c) *dst++ = c;
+            auto const& r = st[fr[s].g1 - 1];
+            std::copy(r.begin(), r.end(), dst);
+            if(S.f_u[s] > 0) S.f_parent[s] = col2front[S.f_rows[S.f_rows_ptr[s]]];
             int const m = S.f_p[s] + S.f_u[s];
             S.max_m = std::max(S.max_m, m);
             S.max_u = std::max(S.max_u, S.f_u[s]);
@@ -518,7 +647,6 @@ namespace pe
                 S.flops += 2.0 * r1 * r1 + r1;
             }
         }
-        for(int j = 0; j < n; ++j) S.nnz_LU += 2LL * static_cast<long long>(st[j].size()) + 1;
         if(S.max_m >= 65536)
         {
             S.error = "front order exceeds 65535";
@@ -548,8 +676,8 @@ namespace pe
         }
         S.f_rel_ptr = S.f_rows_ptr;
         S.f_rel.assign(S.f_rows.size(), -1);
+        ivec depth(nf, 1);
         {
-            ivec depth(nf, 1);
             for(int s = nf - 1; s >= 0; --s)
             {
                 int const P = S.f_parent[s];
@@ -619,48 +747,144 @@ namespace pe
             }
         }
 
-        // storage offsets: factor panels, and the update-matrix stack (postorder => children are on top)
-        S.f_lptr.resize(nf);
-        S.f_uptr.resize(nf);
-        S.f_sptr.resize(nf);
-        long long fo = 0, sp = 0, peak = 0;
+        // ---------------- schedule: wave subtrees (phase 1) + cooperative fronts (phase 2)
+        // a front is a WAVE front when it and its whole subtree fit one wavefront's LDS slot
+        S.f_kind.assign(nf, 0);
         for(int s = 0; s < nf; ++s)
         {
-            long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
-            S.f_lptr[s] = fo;
-            fo += m * p;
-            S.f_uptr[s] = fo;
-            fo += p * u;
-            for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
-            {
-                long long const uc = S.f_u[S.f_child[a]];
-                sp -= uc * uc;
-            }
-            S.f_sptr[s] = sp;
-            sp += u * u;
-            peak = std::max(peak, sp);
+            bool wave = (S.f_p[s] + S.f_u[s]) <= opt.wave_m && S.f_p[s] <= opt.wave_p;
+            for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1] && wave; ++a) wave = S.f_kind[S.f_child[a]] == 0;
+            S.f_kind[s] = wave ? 0 : 1;
         }
-        // the stack discipline requires each front's children to sit contiguously on top when it runs
+        int const W = std::max(1, opt.n_waves);
         {
-            long long chk = 0;
+            // subtree roots = wave fronts whose parent is cooperative (or absent); LPT assignment to W waves
+            ivec root_of(nf, -1);
+            std::vector<double> cost(nf, 0.0);
+            for(int s = nf - 1; s >= 0; --s)
+            {
+                if(S.f_kind[s] != 0) continue;
+                int const P = S.f_parent[s];
+                root_of[s] = (P >= 0 && S.f_kind[P] == 0) ? root_of[P] : s;
+            }
             for(int s = 0; s < nf; ++s)
             {
-                long long kids = 0;
-                for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+                if(S.f_kind[s] != 0) continue;
+                double const m = S.f_p[s] + S.f_u[s];
+                cost[root_of[s]] += 400.0 + m * m * (2.0 + S.f_p[s]);
+            }
+            ivec roots;
+            for(int s = 0; s < nf; ++s)
+                if(S.f_kind[s] == 0 && root_of[s] == s) roots.push_back(s);
+            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
+            std::vector<double> load(W, 0.0);
+            ivec wave_of_root(nf, -1);
+            for(int r: roots)
+            {
+                int const w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+                load[w] += cost[r];
+                wave_of_root[r] = w;
+            }
+            std::vector<ivec> lists(W);
+            for(int s = 0; s < nf; ++s)
+                if(S.f_kind[s] == 0) lists[wave_of_root[root_of[s]]].push_back(s);  // ascending = postorder
+            S.wave_ptr.assign(W + 1, 0);
+            for(int w = 0; w < W; ++w) S.wave_ptr[w + 1] = S.wave_ptr[w] + static_cast<int>(lists[w].size());
+            S.wave_list.clear();
+            for(int w = 0; w < W; ++w) S.wave_list.insert(S.wave_list.end(), lists[w].begin(), lists[w].end());
+            S.coop_list.clear();
+            for(int s = 0; s < nf; ++s)
+                if(S.f_kind[s] == 1) S.coop_list.push_back(s);
+
+            // storage offsets: factor panels
+            S.f_lptr.resize(nf);
+            S.f_uptr.resize(nf);
+            S.f_sptr.assign(nf, 0);
+            long long fo = 0;
+            for(int s = 0; s < nf; ++s)
+            {
+                long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
+                S.f_lptr[s] = fo;
+                fo += m * p;
+                S.f_uptr[s] = fo;
+                fo += p * u;
+            }
+            S.factor_doubles = fo;
+            // update-matrix arena: [persistent: roots of wave subtrees][one stack per wave][cooperative stack]
+            long long base = 0;
+            for(int r: roots)
+            {
+                S.f_sptr[r] = base;
+                base += static_cast<long long>(S.f_u[r]) * S.f_u[r];
+            }
+            for(int w = 0; w < W; ++w)
+            {
+                long long sp = 0, peak = 0;
+                for(int s: lists[w])
                 {
-                    long long const uc = S.f_u[S.f_child[a]];
-                    kids += uc * uc;
+                    for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+                    {
+                        long long const uc = S.f_u[S.f_child[a]];
+                        sp -= uc * uc;  // children of a non-root wave front are non-root wave fronts of the same wave
+                    }
+                    if(root_of[s] == s) continue;  // roots live in the persistent region
+                    S.f_sptr[s] = base + sp;
+                    sp += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                    peak = std::max(peak, sp);
                 }
-                if(S.f_sptr[s] != chk - kids)
+                if(sp != 0)
                 {
-                    S.error = "internal: update stack is not LIFO";
+                    S.error = "internal: wave stack not empty at the end";
                     return false;
                 }
-                chk = S.f_sptr[s] + static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                base += peak;
+            }
+            {
+                // Cooperative fronts write their update matrix while other wavefronts still gather from the children's,
+                // so a parent must never overlap its children: two LIFO stacks, chosen by the parity of the tree depth
+                // (children always live on the other stack; both stay LIFO in postorder).
+                long long sp[2] = {0, 0}, peak[2] = {0, 0};
+                std::vector<long long> rel_off(nf, 0);
+                for(int s: S.coop_list)
+                {
+                    int const q = depth[s] & 1;
+                    for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+                    {
+                        int const c = S.f_child[a];
+                        if(S.f_kind[c] == 1) sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
+                    }
+                    rel_off[s] = sp[q];
+                    sp[q] += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                    peak[q] = std::max(peak[q], sp[q]);
+                }
+                if(sp[0] != 0 || sp[1] != 0)
+                {
+                    // roots have u == 0, so both stacks must be empty at the end
+                    S.error = "internal: cooperative stacks not empty at the end";
+                    return false;
+                }
+                for(int s: S.coop_list) S.f_sptr[s] = base + ((depth[s] & 1) ? peak[0] : 0) + rel_off[s];
+                base += peak[0] + peak[1];
+                S.work_doubles = 0;
+            }
+            S.arena_doubles = base;
+        }
+        // inverse relative maps (cooperative parents only)
+        S.f_inv_off.assign(S.f_child.size(), -1);
+        S.f_inv.clear();
+        for(int s = 0; s < nf; ++s)
+        {
+            if(S.f_kind[s] != 1) continue;
+            int const m = S.f_p[s] + S.f_u[s];
+            for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+            {
+                int const c = S.f_child[a];
+                S.f_inv_off[a] = static_cast<long long>(S.f_inv.size());
+                S.f_inv.resize(S.f_inv.size() + m, -1);
+                int* inv = S.f_inv.data() + S.f_inv_off[a];
+                for(int i = 0; i < S.f_u[c]; ++i) inv[S.f_rel[S.f_rows_ptr[c] + i]] = i;
             }
         }
-        S.factor_doubles = fo;
-        S.arena_doubles = peak;
         return true;
     }
 }  // namespace pe

@@ -19,8 +19,15 @@ namespace pe
         int nd_leaf{48};          // stop dissecting below this many vertices
         int relax_small{8};       // always merge a last child into its parent while the merged front has <= this many pivots
         double relax_zero_frac{0.30};  // otherwise merge only if the explicit zeros added stay below this fraction of the merged panel
-        int max_pivots{96};       // never grow a front beyond this many pivots (chains are split)
+        int max_pivots{48};       // never grow a front beyond this many pivots (chains are split)
         double match_diag_rel{1e-8};   // keep a_jj as pivot when |a_jj| >= rel * max|row|
+        // GPU mapping limits (see pe_front.hpp): a WAVE front (m <= wave_m, p <= wave_p) is factorised by one
+        // wavefront in its own LDS slot; larger fronts are COOPERATIVE: the whole workgroup, pivot panels in LDS
+        int wave_m{48};
+        int wave_p{24};
+        int absorb_m{32};         // a parent absorbs any child while the merged front order stays <= absorb_m
+        int n_waves{8};           // wavefronts per workgroup (static assignment of wave subtrees)
+        long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
 
     struct Symbolic
@@ -49,6 +56,14 @@ namespace pe
         std::vector<long long> f_sptr;          // offset of the u x u update matrix in the stack arena
         long long factor_doubles{};
         long long arena_doubles{};
+        long long work_doubles{};               // largest u*u of a cooperative front (global Schur workspace)
+        std::vector<int> f_kind;                // 0: wave front, 1: cooperative front
+        std::vector<int> wave_ptr, wave_list;   // phase 1: fronts of wave w = wave_list[wave_ptr[w] .. wave_ptr[w+1]) in postorder
+        std::vector<int> coop_list;             // phase 2: cooperative fronts in postorder
+        // pull-based assembly of cooperative fronts: for child edge e (position in f_child) of a cooperative parent,
+        // f_inv[f_inv_off[e] + r] = index of parent-local row r among the child's update rows, or -1
+        std::vector<long long> f_inv_off;
+        std::vector<int> f_inv;
         int max_m{};                            // largest front order
         int max_u{};
 

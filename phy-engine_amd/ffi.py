@@ -24,7 +24,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
-    "pe_hip_analyze_pattern_fronts",
+    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks",
 ]
 
 
@@ -295,6 +295,15 @@ class Engine:
         rhs = np.empty(self.rows)
         self._chk(lib().pe_hip_get_matrix(self._h, instance, _ip(rp), _ip(ci), _dp(va), _dp(rhs)))
         return rp, ci, va, rhs
+
+    def phase_clocks(self, instance=0):
+        """In-kernel phase times of one instance since reset(), in microseconds (see pe_hip_get_phase_clocks)."""
+        t = np.zeros(8, dtype=np.int64)
+        fn = lib().pe_hip_get_phase_clocks
+        fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
+        self._chk(fn(self._h, instance, t.ctypes.data_as(C.POINTER(C.c_longlong))))
+        names = ["eval_stamp", "lu_wave", "lu_coop", "fwd_wave", "fwdbwd_coop", "bwd_wave", "coop_asm", "coop_piv"]
+        return {n: float(t[i]) / 100.0 for i, n in enumerate(names)}
 
     def update_param(self, kind, index, column, values):
         v = np.atleast_1d(np.asarray(values, dtype=np.float64))

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Developer tool: GPU time per Newton iteration + in-kernel phase breakdown on the M10k mesh (B = 1 and B = N)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pe_load
+pe = pe_load.load()
+W = int(os.environ.get("MESH", "100"))
+for nonlinear in (False, True):
+    for B in [int(x) for x in os.environ.get("BATCHES", "1,128").split(",")]:
+        seeds = list(range(1, B + 1))
+        deck, r, c = pe.deck.rc_mesh_params(W, W, seeds, nonlinear)
+        eng = pe.ffi.Engine()
+        eng.set_options(g_min=0.0)
+        eng.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
+        eng.reset()
+        eng.analyze_tr(1e-10, 2)
+        eng.reset()
+        st = eng.analyze_tr(1e-10, 20)
+        it = st["newton_iters"] / B
+        ph = eng.phase_clocks(0)
+        tot = sum(ph.values())
+        print(f"mesh{W} {'NL' if nonlinear else 'lin'} B={B}: {st['gpu_ms']/20:.3f} ms/step, {st['gpu_ms']/it:.3f} ms/iter(instance 0 stream), iters/step={it/20:.2f} "
+              f"agg iters/s={st['newton_iters']/st['gpu_ms']*1e3:.0f} | phases us/iter: " + " ".join(f"{k}={v/it:.0f}" for k, v in ph.items()) + f" sum={tot/it:.0f}", flush=True)
+        eng.close()

@@ -1,6 +1,6 @@
-// tests/emu/pe_kernels_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the team-generic code of pe_front.hpp with a
-// one-thread team per instance on the host (see hip_shim/hip/hip_runtime_api.h).  Checks indexing and the
-// orchestration; says nothing about races or performance.
+// tests/emu/pe_kernels_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the team-generic code of pe_front.hpp on the host
+// with a one-thread team per instance and one-lane "wavefronts" executed one after the other (see
+// hip_shim/hip/hip_runtime_api.h).  Checks indexing and the orchestration; says nothing about races or performance.
 #include <vector>
 
 #include "pe_front.hpp"
@@ -10,38 +10,96 @@ namespace pe
 {
     struct SerialTeam
     {
+        int nw;
         int tid() const { return 0; }
         int size() const { return 1; }
         void sync() const {}
         int sync_or(int v) const { return v; }
+        int lanes() const { return 1; }
+        long long clock() const { return 0; }
+        void wave_fence() const {}
+        template <class F>
+        void for_each_wave(F&& body) const
+        {
+            for(int w = 0; w < nw; ++w) body(w, 0, 1);
+        }
+        int n_waves() const { return nw; }
+        int diag_lu8(double* blk, int ld, int kb, int) const
+        {
+            for(int kk = 0; kk < kb; ++kk)
+            {
+                double const piv = blk[kk + kk * ld];
+                if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
+                for(int r = kk + 1; r < kb; ++r)
+                {
+                    double const l = blk[r + kk * ld] / piv;
+                    for(int c = kk + 1; c < kb; ++c) blk[r + c * ld] -= l * blk[kk + c * ld];
+                    blk[r + kk * ld] = l;
+                }
+            }
+            return 0;
+        }
+        // plain-loop stand-in for the 16 x 16 matrix-core tiles
+        struct Acc
+        {
+            double v[16][16];
+        };
+        Acc tile_zero() const
+        {
+            Acc a;
+            for(auto& r: a.v)
+                for(double& x: r) x = 0.0;
+            return a;
+        }
+        Acc tile_load(double const* C, int ldc, int mr, int nc, int) const
+        {
+            Acc a = tile_zero();
+            for(int c = 0; c < nc; ++c)
+                for(int r = 0; r < mr; ++r) a.v[r][c] = C[r + c * ldc];
+            return a;
+        }
+        void tile_store(Acc const& a, double* C, int ldc, int mr, int nc, int) const
+        {
+            for(int c = 0; c < nc; ++c)
+                for(int r = 0; r < mr; ++r) C[r + c * ldc] = a.v[r][c];
+        }
+        void tile_mulsub(Acc& a, double const* A, int lda, double const* B, int ldb, int mr, int nc, int kd, int) const
+        {
+            for(int k = 0; k < kd; ++k)
+                for(int c = 0; c < nc; ++c)
+                    for(int r = 0; r < mr; ++r) a.v[r][c] -= A[r + k * lda] * B[k + c * ldb];
+        }
+        template <class F>
+        void tile_foreach(Acc& a, int, F&& f) const
+        {
+            for(int c = 0; c < 16; ++c)
+                for(int r = 0; r < 16; ++r) f(r, c, a.v[r][c]);
+        }
     };
 
-    size_t lds_bytes_for(DevView const& V, int max_m) { return (static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap + static_cast<size_t>(max_m) + 2) * sizeof(double); }
-
-    hipError_t launch_tr_steps(hipStream_t, DevView const& V, double dt, int nsteps, bool reuse, size_t lds)
+    hipError_t launch_tr_steps(hipStream_t, DevView const& V, double dt, int nsteps, bool reuse)
     {
-        std::vector<double> mem(lds / sizeof(double) + 1);
-        for(int b = 0; b < V.batch; ++b)
-            tr_steps(SerialTeam{}, V, b, dt, nsteps, reuse, mem.data(), mem.data() + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap);
+        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        for(int b = 0; b < V.batch; ++b) tr_steps(SerialTeam{V.n_waves}, V, b, dt, nsteps, reuse, mem.data());
         return hipSuccess;
     }
-    hipError_t launch_dc_point(hipStream_t, DevView const& V, int mode, size_t lds)
+    hipError_t launch_dc_point(hipStream_t, DevView const& V, int mode)
     {
-        std::vector<double> mem(lds / sizeof(double) + 1);
-        for(int b = 0; b < V.batch; ++b) dc_point(SerialTeam{}, V, b, mode, mem.data(), mem.data() + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap);
+        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        for(int b = 0; b < V.batch; ++b) dc_point(SerialTeam{V.n_waves}, V, b, mode, mem.data());
         return hipSuccess;
     }
-    hipError_t launch_factor_solve(hipStream_t, DevView const& V, bool do_factor, size_t lds)
+    hipError_t launch_factor_solve(hipStream_t, DevView const& V, bool do_factor)
     {
-        std::vector<double> mem(lds / sizeof(double) + 1);
-        SerialTeam tm;
+        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        SerialTeam tm{V.n_waves};
         for(int b = 0; b < V.batch; ++b)
         {
             int st = ST_OK;
             if(do_factor && !factor_all(tm, V, b, mem.data())) st = ST_SINGULAR;
             if(st == ST_OK)
             {
-                solve_all(tm, V, b, mem.data() + static_cast<size_t>(V.lds_front_cap) * V.lds_front_cap);
+                solve_all(tm, V, b, mem.data());
                 double const* x = V.x + static_cast<long long>(b) * V.rows;
                 for(int r = 0; r < V.rows; ++r)
                     if(!(std::fabs(x[r]) <= 1.7976931348623157e308)) st = ST_SINGULAR;
