@@ -85,8 +85,8 @@ namespace pe
         // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts
         int const *wave_ptr, *wave_list, *coop_list;
         int n_coop, n_waves;
-        int wave_m, max_m, max_p;
-        int lds_slot;           // doubles of one wavefront's front slot (wave_m * wave_m)
+        int wave_m, wave_p, max_m, max_p;
+        int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)
         int lds_sslot;          // doubles of one wavefront's solve scratch
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
         // ---- Newton

@@ -162,8 +162,9 @@ namespace
         V.wave_m = so.wave_m;
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
-        V.lds_slot = so.wave_m * so.wave_m;
-        V.lds_sslot = so.wave_m + so.wave_m * so.wave_p;
+        V.wave_p = so.wave_p;
+        V.lds_slot = static_cast<int>(S.wave_panel_doubles);
+        V.lds_sslot = so.wave_m + so.wave_p * so.wave_p + 64;  // t[m] + staged p x p block + partial sums of one wavefront
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
             need = std::max(need, so.panel_doubles);
@@ -179,10 +180,29 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
-    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h)
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch)
     {
         pe::SymbolicOptions so{};
-        so.n_waves = PE_THREADS / 64;
+        // workgroup geometry by batch size (measured on MI355X, profiles/): few instances -> one big workgroup per CU;
+        // a sweep that oversubscribes the 256 CUs -> smaller workgroups, 2-4 resident per CU
+        if(batch >= 768)
+        {
+            so.n_waves = 4;
+            so.wave_m = 32;
+            so.max_pivots = 32;
+        }
+        else if(batch >= 384)
+        {
+            so.n_waves = 8;
+            so.wave_m = 32;
+            so.max_pivots = 32;
+        }
+        else
+        {
+            so.n_waves = 8;
+            so.wave_m = 48;
+            so.max_pivots = 48;
+        }
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
         auto env_int = [](char const* name, int def)
         {
@@ -195,8 +215,10 @@ namespace
         so.absorb_m = std::max(1, env_int("PHY_ENGINE_HIP_ABSORB_M", so.absorb_m));
         so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
         so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
+        so.wave_p = std::min(so.wave_p, so.max_pivots);
         long long const lds_doubles = h->lds_limit / 8 - 16;
-        while(static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
+        // a wave front needs p * (m + u) <= wave_p * 2 * wave_m doubles of LDS; keep all wavefronts' slots within the limit
+        while(static_cast<long long>(so.n_waves) * so.wave_p * 2 * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
         so.panel_doubles = std::min<long long>(lds_doubles, static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m);
         return so;
@@ -209,7 +231,7 @@ namespace
         auto const t0 = clk::now();
         std::vector<double> av;
         pe::estimate_values(h->hc, tr, dt, h->opt.g_min, av);
-        pe::SymbolicOptions const so = symbolic_options(h);
+        pe::SymbolicOptions const so = symbolic_options(h, h->hc.batch);
         if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
         {
             h->sym_class = -1;
@@ -717,7 +739,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
         auto const t0 = clk::now();
         C.have = false;
         C.pool.release();
-        pe::SymbolicOptions const so = symbolic_options(h);
+        pe::SymbolicOptions const so = symbolic_options(h, 1);
         if(!pe::analyze(n, row_ptr, col_ind, values, so, C.sym))
             return fail(h, C.sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "solve_csr_real: " + C.sym.error);
         pe::DevView V{};

@@ -307,123 +307,8 @@ namespace pe
         }
     }
 
-    // ---- one WAVE front, executed by ONE wavefront (lane, NL) with F (m x m, ld m) in that wave's LDS slot
-    template <class Team>
-    PE_DEV bool wave_factor_front(Team const& tm, DevView const& V, int b, int s, double* F, int lane, int NL)
-    {
-        int const p = V.f_p[s], u = V.f_u[s], m = p + u;
-        double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
-        double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
-        double* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
-        for(int i = lane; i < m * m; i += NL) F[i] = 0.0;
-        tm.wave_fence();
-        {
-            int const e0 = V.f_asm_ptr[s], e1 = V.f_asm_ptr[s + 1];
-            for(int base = e0 + lane; base < e1; base += 2 * NL)
-            {
-                int const eb = base + NL;
-                int const pa = V.asm_pos[base], sa = V.asm_slot[base];
-                int const pb = eb < e1 ? V.asm_pos[eb] : 0, sb = eb < e1 ? V.asm_slot[eb] : 0;
-                double const va = a[sa];
-                double const vb = eb < e1 ? a[sb] : 0.0;
-                F[(pa >> 16) + (pa & 0xffff) * m] = va;
-                if(eb < e1) F[(pb >> 16) + (pb & 0xffff) * m] = vb;
-            }
-        }
-        tm.wave_fence();
-        for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
-        {
-            int const c = V.f_child[ch];
-            int const uc = V.f_u[c];
-            double const* Sc = arena + V.f_sptr[c];
-            int const* rel = V.f_rel + V.f_rows_ptr[c];
-            float const rcp = 1.0f / static_cast<float>(uc);
-            int const n = uc * uc;
-            for(int base = lane; base < n; base += 4 * NL)
-            {
-                double v[4];
-                int d[4];
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
-                {
-                    int const idx = base + q * NL;
-                    bool const ok = idx < n;
-                    int const j = ok ? fdiv(idx, rcp) : 0, i = ok ? idx - j * uc : 0;
-                    d[q] = rel[i] + rel[j] * m;
-                    v[q] = ok ? Sc[idx] : 0.0;
-                }
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
-                    if(base + q * NL < n) F[d[q]] += v[q];
-            }
-            tm.wave_fence();
-        }
-        int const BX = NL >= 64 ? 8 : 1, BY = NL / BX;
-        int const li = lane % BX, lj = lane / BX;
-        for(int k = 0; k < p; ++k)
-        {
-            double const piv = F[k + k * m];
-            if(bad_pivot(piv)) return false;  // uniform over the wavefront
-            double const inv = 1.0 / piv;
-            for(int i = k + 1 + li; i < m; i += BX)
-            {
-                double const lik = F[i + k * m] * inv;
-                // loads of a batch are issued together, then the stores: LDS latency is paid once per batch
-                for(int j0 = k + 1 + lj; j0 < m; j0 += 4 * BY)
-                {
-                    double f[4], ur[4];
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        int const j = j0 + q * BY;
-                        bool const in = j < m;
-                        f[q] = in ? F[i + j * m] : 0.0;
-                        ur[q] = in ? F[k + j * m] : 0.0;
-                    }
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        int const j = j0 + q * BY;
-                        if(j < m) F[i + j * m] = f[q] - lik * ur[q];
-                    }
-                }
-            }
-            tm.wave_fence();
-        }
-        double* Lp = fac + V.f_lptr[s];
-        for(int k = 0; k < p; ++k)
-        {
-            double const inv = 1.0 / F[k + k * m];
-            for(int i = lane; i < m; i += NL)
-            {
-                double const v = F[i + k * m];
-                Lp[i + k * m] = i > k ? v * inv : v;
-            }
-        }
-        double* Up = fac + V.f_uptr[s];
-        {
-            float const rcp = 1.0f / static_cast<float>(p);
-            for(int idx = lane; idx < p * u; idx += NL)
-            {
-                int const j = fdiv(idx, rcp), k = idx - j * p;
-                Up[idx] = F[k + (p + j) * m];
-            }
-        }
-        double* Ss = arena + V.f_sptr[s];
-        if(u > 0)
-        {
-            float const rcp = 1.0f / static_cast<float>(u);
-            for(int idx = lane; idx < u * u; idx += NL)
-            {
-                int const j = fdiv(idx, rcp), i = idx - j * u;
-                Ss[idx] = F[(p + i) + (p + j) * m];
-            }
-        }
-        tm.wave_fence();
-        return true;
-    }
-
-    // ---- one COOPERATIVE front, executed by the whole team; Lp (m x p, ld m) and Up (p x u, ld p) in LDS.
+    // ---- one front, executed by a TEAM: the whole workgroup (cooperative fronts) or a single wavefront (wave
+    // fronts, through tm.wave_team()); Lp (m x p, ld m) and Up (p x u, ld p) live in the team's LDS region.
     //
     // Blocked right-looking LU of the pivot panels, block = 16 pivots:
     //   (a0) wavefront 0 factors the 16 x 16 diagonal block in LDS (no workgroup barrier inside),
@@ -432,7 +317,7 @@ namespace pe
     // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
     // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
     template <class Team>
-    PE_DEV bool coop_factor_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s, double* lds, bool profile)
     {
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
         double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
@@ -510,53 +395,59 @@ namespace pe
                 int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
                 int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
                 int const ncols = ncolL + u;              // plus every column of the U panel
-                if(t0 < nrows + ncols || T < nrows + ncols)
+                for(int q = t0; q < nrows + ncols; q += T)
                 {
-                    double Bk[NB][NB];
-#pragma unroll
-                    for(int c = 0; c < NB; ++c)
-#pragma unroll
-                        for(int r = 0; r < NB; ++r) Bk[r][c] = (r < kb && c < kb) ? Lp[(k0 + r) + (k0 + c) * m] : (r == c ? 1.0 : 0.0);
-                    for(int q = t0; q < nrows + ncols; q += T)
+                    double x[NB];
+                    if(q < nrows)
                     {
-                        double x[NB];
-                        if(q < nrows)
+                        // x * U11 = a  (row of L): needs the upper triangle of the block
+                        double* row = Lp + (k0 + kb + q) + k0 * m;
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk)
                         {
-                            double* row = Lp + (k0 + kb + q) + k0 * m;
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
+                            if(kk < kb)
                             {
+                                double ucol[NB];
+#pragma unroll
+                                for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? Lp[(k0 + r) + (k0 + kk) * m] : 0.0;
                                 double acc = x[kk];
 #pragma unroll
                                 for(int r = 0; r < NB; ++r)
-                                    if(r < kk) acc -= x[r] * Bk[r][kk];
-                                x[kk] = acc / Bk[kk][kk];
+                                    if(r < kk) acc -= x[r] * ucol[r];
+                                x[kk] = acc / ucol[kk];
                             }
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
-                                if(kk < kb) row[kk * m] = x[kk];
                         }
-                        else
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk)
+                            if(kk < kb) row[kk * m] = x[kk];
+                    }
+                    else
+                    {
+                        // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
+                        int const jc = q - nrows;
+                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * p + k0;
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
+#pragma unroll
+                        for(int kk = 1; kk < NB; ++kk)
                         {
-                            int const jc = q - nrows;
-                            double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * p + k0;
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
+                            if(kk < kb)
                             {
+                                double lrow[NB];
+#pragma unroll
+                                for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? Lp[(k0 + kk) + (k0 + r) * m] : 0.0;
                                 double acc = x[kk];
 #pragma unroll
                                 for(int r = 0; r < NB; ++r)
-                                    if(r < kk) acc -= Bk[kk][r] * x[r];
+                                    if(r < kk) acc -= lrow[r] * x[r];
                                 x[kk] = acc;
                             }
-#pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
-                                if(kk < kb) col[kk] = x[kk];
                         }
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk)
+                            if(kk < kb) col[kk] = x[kk];
                     }
                 }
             }
@@ -608,7 +499,7 @@ namespace pe
             }
             tm.sync();
         }
-        if(V.prof && t0 == 0)
+        if(profile && V.prof && t0 == 0)
         {
             V.prof[b * 8 + 6] += ck1 - ck0;
             V.prof[b * 8 + 7] += tm.clock() - ck1;
@@ -662,9 +553,10 @@ namespace pe
         tm.for_each_wave(
             [&](int w, int lane, int NL)
             {
-                double* F = lds + static_cast<long long>(w) * V.lds_slot;
+                auto wt = tm.wave_team(lane);
+                double* slot = lds + static_cast<long long>(w) * V.lds_slot;
                 for(int q = V.wave_ptr[w]; q < V.wave_ptr[w + 1]; ++q)
-                    if(!wave_factor_front(tm, V, b, V.wave_list[q], F, lane, NL))
+                    if(!front_factor(wt, V, b, V.wave_list[q], slot, false))
                     {
                         fail = 1;
                         break;
@@ -673,7 +565,7 @@ namespace pe
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
         for(int q = 0; q < V.n_coop; ++q)
-            if(!coop_factor_front(tm, V, b, V.coop_list[q], lds)) return false;
+            if(!front_factor(tm, V, b, V.coop_list[q], lds, true)) return false;
         if(V.prof && tm.tid() == 0)
         {
             V.prof[b * 8 + 1] += c1 - c0;
@@ -688,94 +580,6 @@ namespace pe
     // up -- pull-based, race-free, deterministic.  Backward: each front gathers the already final unknowns of its
     // ancestors.  w is the permuted right-hand side / solution.
     // ================================================================================================
-    template <class Team>
-    PE_DEV void wave_forward_front(Team const& tm, DevView const& V, int b, int s, double* sc, int lane, int NL)
-    {
-        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-        double* w = V.w + static_cast<long long>(b) * V.rows;
-        double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
-        double const* Lg = V.factor + static_cast<long long>(b) * V.factor_doubles + V.f_lptr[s];
-        double* t = sc;              // [m]
-        double* Ls = sc + V.wave_m;  // staged L panel [m x p]
-        for(int i = lane; i < m; i += NL) t[i] = i < p ? w[c0 + i] : 0.0;
-        stage_copy<8>(Ls, Lg, m * p, lane, NL);
-        tm.wave_fence();
-        for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
-        {
-            int const c = V.f_child[ch];
-            double const* uc = arena + V.f_sptr[c];
-            int const* rel = V.f_rel + V.f_rows_ptr[c];
-            for(int i = lane; i < V.f_u[c]; i += NL) t[rel[i]] += uc[i];
-            tm.wave_fence();
-        }
-        for(int k = 0; k + 1 < p; ++k)
-        {
-            double const yk = t[k];
-            for(int i = k + 1 + lane; i < p; i += NL) t[i] -= Ls[i + k * m] * yk;
-            tm.wave_fence();
-        }
-        for(int i = lane; i < p; i += NL) w[c0 + i] = t[i];
-        double* us = arena + V.f_sptr[s];
-        for(int i = lane; i < u; i += NL)
-        {
-            double acc = t[p + i];
-            for(int k = 0; k < p; ++k) acc -= Ls[(p + i) + k * m] * t[k];
-            us[i] = acc;
-        }
-        tm.wave_fence();
-    }
-
-    template <class Team>
-    PE_DEV void wave_backward_front(Team const& tm, DevView const& V, int b, int s, double* sc, int lane, int NL)
-    {
-        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-        double* w = V.w + static_cast<long long>(b) * V.rows;
-        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
-        double const* Lg = fac + V.f_lptr[s];
-        double const* Ug = fac + V.f_uptr[s];
-        int const* rows = V.f_rows + V.f_rows_ptr[s];
-        double* t = sc;                // [m]: t[0..p) rhs/solution, t[p..m) gathered ancestors
-        double* Us = sc + V.wave_m;    // staged [L11\U11 block (p x p, ld p) | U12 (p x u, ld p)]
-        for(int j = lane; j < u; j += NL) t[p + j] = w[rows[j]];
-        for(int i = lane; i < p; i += NL) t[i] = w[c0 + i];
-        {
-            float const rp = 1.0f / static_cast<float>(p);
-            int const n = p * p;
-            for(int base = lane; base < n; base += 4 * NL)
-            {
-                double r[4];
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
-                {
-                    int const idx = base + q * NL;
-                    int const k = idx < n ? fdiv(idx, rp) : 0, i = idx < n ? idx - k * p : 0;
-                    r[q] = Lg[i + k * m];
-                }
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
-                    if(base + q * NL < n) Us[base + q * NL] = r[q];
-            }
-        }
-        stage_copy<8>(Us + p * p, Ug, p * u, lane, NL);
-        tm.wave_fence();
-        for(int k = lane; k < p; k += NL)
-        {
-            double acc = t[k];
-            for(int j = 0; j < u; ++j) acc -= Us[p * p + k + j * p] * t[p + j];
-            t[k] = acc;
-        }
-        tm.wave_fence();
-        for(int k = p - 1; k >= 0; --k)
-        {
-            double const xk = t[k] / Us[k + k * p];
-            for(int i = lane; i < k; i += NL) t[i] -= Us[i + k * p] * xk;
-            if(lane == 0) t[k] = xk;
-            tm.wave_fence();
-        }
-        for(int i = lane; i < p; i += NL) w[c0 + i] = t[i];
-        tm.wave_fence();
-    }
-
     // out[i] (i < nrow) = init[i] - sum_k A[i + k*lda] * x[k]  (k < ncol), A in global memory, x in LDS.
     // All T threads: thread = (row, column chunk); partial sums meet in LDS `part` (>= T doubles).
     template <class Team>
@@ -805,16 +609,16 @@ namespace pe
     }
 
     template <class Team>
-    PE_DEV void coop_forward_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    PE_DEV void front_forward(Team const& tm, DevView const& V, int b, int s, double* lds, int cap_m, int cap_p)
     {
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-        int const T = tm.size(), t0 = tm.tid(), NL = tm.lanes();
+        int const T = tm.size(), t0 = tm.tid();
         double* w = V.w + static_cast<long long>(b) * V.rows;
         double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
         double const* Lg = V.factor + static_cast<long long>(b) * V.factor_doubles + V.f_lptr[s];
         double* t = lds;                              // [m]
-        double* Lb = lds + V.max_m;                   // staged L11 [p x p, ld p]
-        double* part = Lb + V.max_p * V.max_p;        // [T]
+        double* Lb = lds + cap_m;                     // staged L11 [p x p, ld p]
+        double* part = Lb + cap_p * cap_p;            // [T]
         for(int i = t0; i < m; i += T) t[i] = i < p ? w[c0 + i] : 0.0;
         {
             float const rp = 1.0f / static_cast<float>(p);
@@ -833,15 +637,17 @@ namespace pe
             for(int i = t0; i < V.f_u[c]; i += T) t[rel[i]] += uc[i];
             tm.sync();
         }
-        if(t0 < NL)  // wavefront 0 runs the dependent chain without workgroup barriers
-        {
-            for(int k = 0; k + 1 < p; ++k)
+        tm.for_each_wave(
+            [&](int w, int lane, int NLw)
             {
-                double const yk = t[k];
-                for(int i = k + 1 + t0; i < p; i += NL) t[i] -= Lb[i + k * p] * yk;
-                tm.wave_fence();
-            }
-        }
+                if(w != 0) return;  // wavefront 0 runs the dependent chain without workgroup barriers
+                for(int k = 0; k + 1 < p; ++k)
+                {
+                    double const yk = t[k];
+                    for(int i = k + 1 + lane; i < p; i += NLw) t[i] -= Lb[i + k * p] * yk;
+                    tm.wave_fence();
+                }
+            });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
         if(u > 0)
@@ -860,18 +666,18 @@ namespace pe
     }
 
     template <class Team>
-    PE_DEV void coop_backward_front(Team const& tm, DevView const& V, int b, int s, double* lds)
+    PE_DEV void front_backward(Team const& tm, DevView const& V, int b, int s, double* lds, int cap_m, int cap_p)
     {
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
-        int const T = tm.size(), t0 = tm.tid(), NL = tm.lanes();
+        int const T = tm.size(), t0 = tm.tid();
         double* w = V.w + static_cast<long long>(b) * V.rows;
         double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
         double const* Lg = fac + V.f_lptr[s];
         double const* Ug = fac + V.f_uptr[s];
         int const* rows = V.f_rows + V.f_rows_ptr[s];
         double* t = lds;                              // [m]
-        double* Ub = lds + V.max_m;                   // staged U11 [p x p, ld p]
-        double* part = Ub + V.max_p * V.max_p;        // [T] partial sums of U12 * x_U
+        double* Ub = lds + cap_m;                     // staged U11 [p x p, ld p]
+        double* part = Ub + cap_p * cap_p;            // [T] partial sums of U12 * x_U
         for(int j = t0; j < u; j += T) t[p + j] = w[rows[j]];
         for(int i = t0; i < p; i += T) t[i] = w[c0 + i];
         {
@@ -895,16 +701,18 @@ namespace pe
             }
             tm.sync();
         }
-        if(t0 < NL)
-        {
-            for(int k = p - 1; k >= 0; --k)
+        tm.for_each_wave(
+            [&](int w, int lane, int NLw)
             {
-                double const xk = t[k] / Ub[k + k * p];
-                for(int i = t0; i < k; i += NL) t[i] -= Ub[i + k * p] * xk;
-                if(t0 == 0) t[k] = xk;
-                tm.wave_fence();
-            }
-        }
+                if(w != 0) return;
+                for(int k = p - 1; k >= 0; --k)
+                {
+                    double const xk = t[k] / Ub[k + k * p];
+                    for(int i = lane; i < k; i += NLw) t[i] -= Ub[i + k * p] * xk;
+                    if(lane == 0) t[k] = xk;
+                    tm.wave_fence();
+                }
+            });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
         tm.sync();
@@ -923,20 +731,22 @@ namespace pe
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
             {
+                auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = V.wave_ptr[wv]; q < V.wave_ptr[wv + 1]; ++q) wave_forward_front(tm, V, b, V.wave_list[q], sc, lane, NL);
+                for(int q = V.wave_ptr[wv]; q < V.wave_ptr[wv + 1]; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
             });
         tm.sync();
         long long const c1 = tm.clock();
-        for(int q = 0; q < V.n_coop; ++q) coop_forward_front(tm, V, b, V.coop_list[q], lds);
-        for(int q = V.n_coop - 1; q >= 0; --q) coop_backward_front(tm, V, b, V.coop_list[q], lds);
+        for(int q = 0; q < V.n_coop; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
+        for(int q = V.n_coop - 1; q >= 0; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
         tm.sync();
         long long const c2 = tm.clock();
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
             {
+                auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = V.wave_ptr[wv + 1] - 1; q >= V.wave_ptr[wv]; --q) wave_backward_front(tm, V, b, V.wave_list[q], sc, lane, NL);
+                for(int q = V.wave_ptr[wv + 1] - 1; q >= V.wave_ptr[wv]; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
             });
         tm.sync();
         if(V.prof && t0 == 0)

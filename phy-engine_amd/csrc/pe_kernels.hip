@@ -12,14 +12,9 @@
 
 namespace pe
 {
-    struct HipTeam
+    // ---- matrix-core / cross-lane primitives shared by the workgroup team and the single-wavefront team
+    struct WaveOps
     {
-        __device__ __forceinline__ int tid() const { return static_cast<int>(threadIdx.x); }
-        __device__ __forceinline__ int size() const { return static_cast<int>(blockDim.x); }
-        __device__ __forceinline__ void sync() const { __syncthreads(); }
-        __device__ __forceinline__ int sync_or(int v) const { return __syncthreads_or(v); }
-        __device__ __forceinline__ int lanes() const { return 64; }
-        __device__ __forceinline__ long long clock() const { return static_cast<long long>(wall_clock64()); }
         // a wavefront's own LDS / global writes become visible to its own later reads (other lanes included)
         __device__ __forceinline__ void wave_fence() const
         {
@@ -27,12 +22,8 @@ namespace pe
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        template <class F>
-        __device__ __forceinline__ void for_each_wave(F&& body) const
-        {
-            body(static_cast<int>(threadIdx.x) >> 6, static_cast<int>(threadIdx.x) & 63, 64);
-        }
-        __device__ __forceinline__ int n_waves() const { return static_cast<int>(blockDim.x) >> 6; }
+        __device__ __forceinline__ int lanes() const { return 64; }
+        __device__ __forceinline__ long long clock() const { return static_cast<long long>(wall_clock64()); }
 
         // LU (no pivoting) of a kb x kb block (kb <= 8) held one entry per lane: lane l <-> (row l&7, col l>>3).
         // The dependent chain runs on cross-lane shuffles, not on LDS round trips.  On return the block in memory
@@ -115,10 +106,48 @@ namespace pe
         }
     };
 
+    // one wavefront acting as a team of 64: barriers degenerate to wavefront fences
+    struct WaveTeam : WaveOps
+    {
+        int lane_;
+        __device__ __forceinline__ int tid() const { return lane_; }
+        __device__ __forceinline__ int size() const { return 64; }
+        __device__ __forceinline__ void sync() const { wave_fence(); }
+        __device__ __forceinline__ int sync_or(int v) const { return __any(v); }
+        __device__ __forceinline__ int n_waves() const { return 1; }
+        template <class F>
+        __device__ __forceinline__ void for_each_wave(F&& body) const
+        {
+            body(0, lane_, 64);
+        }
+        __device__ __forceinline__ WaveTeam wave_team(int) const { return *this; }
+    };
+
+    // the whole workgroup
+    struct HipTeam : WaveOps
+    {
+        __device__ __forceinline__ int tid() const { return static_cast<int>(threadIdx.x); }
+        __device__ __forceinline__ int size() const { return static_cast<int>(blockDim.x); }
+        __device__ __forceinline__ void sync() const { __syncthreads(); }
+        __device__ __forceinline__ int sync_or(int v) const { return __syncthreads_or(v); }
+        __device__ __forceinline__ int n_waves() const { return static_cast<int>(blockDim.x) >> 6; }
+        template <class F>
+        __device__ __forceinline__ void for_each_wave(F&& body) const
+        {
+            body(static_cast<int>(threadIdx.x) >> 6, static_cast<int>(threadIdx.x) & 63, 64);
+        }
+        __device__ __forceinline__ WaveTeam wave_team(int lane) const
+        {
+            WaveTeam w;
+            w.lane_ = lane;
+            return w;
+        }
+    };
+
     // dynamic LDS: V.lds_doubles doubles, carved per phase by pe_front.hpp
     extern __shared__ __attribute__((aligned(16))) double pe_lds[];
 
-    __global__ void __launch_bounds__(PE_THREADS) k_tr_steps(DevView V, double dt, int nsteps, int reuse_factor)
+    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_tr_steps(DevView V, double dt, int nsteps, int reuse_factor)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
@@ -126,7 +155,7 @@ namespace pe
         tr_steps(tm, V, b, dt, nsteps, reuse_factor != 0, pe_lds);
     }
 
-    __global__ void __launch_bounds__(PE_THREADS) k_dc_point(DevView V, int mode)
+    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_dc_point(DevView V, int mode)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
@@ -135,7 +164,7 @@ namespace pe
     }
 
     // A x = b with A values / rhs already resident (solve_csr_real seam): factor + solve, instance 0..batch-1
-    __global__ void __launch_bounds__(PE_THREADS) k_factor_solve(DevView V, int do_factor)
+    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_factor_solve(DevView V, int do_factor)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;

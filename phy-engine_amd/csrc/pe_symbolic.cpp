@@ -817,27 +817,38 @@ namespace pe
                 S.f_sptr[r] = base;
                 base += static_cast<long long>(S.f_u[r]) * S.f_u[r];
             }
+            // A front writes its update matrix tile by tile while later tiles still gather from its children's, so a
+            // parent must never overlap its children: TWO LIFO stacks per executor (each wavefront, and the
+            // cooperative phase), chosen by the parity of the tree depth -- children always sit on the other stack.
             for(int w = 0; w < W; ++w)
             {
-                long long sp = 0, peak = 0;
-                for(int s: lists[w])
+                long long sp[2] = {0, 0}, peak[2] = {0, 0};
+                std::vector<long long> rel_off(lists[w].size(), 0);
+                for(size_t qi = 0; qi < lists[w].size(); ++qi)
                 {
+                    int const s = lists[w][qi];
                     for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
                     {
-                        long long const uc = S.f_u[S.f_child[a]];
-                        sp -= uc * uc;  // children of a non-root wave front are non-root wave fronts of the same wave
+                        int const c = S.f_child[a];  // children of a wave front are non-root wave fronts of the same wave
+                        sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
                     }
                     if(root_of[s] == s) continue;  // roots live in the persistent region
-                    S.f_sptr[s] = base + sp;
-                    sp += static_cast<long long>(S.f_u[s]) * S.f_u[s];
-                    peak = std::max(peak, sp);
+                    int const q = depth[s] & 1;
+                    rel_off[qi] = sp[q];
+                    sp[q] += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                    peak[q] = std::max(peak[q], sp[q]);
                 }
-                if(sp != 0)
+                if(sp[0] != 0 || sp[1] != 0)
                 {
-                    S.error = "internal: wave stack not empty at the end";
+                    S.error = "internal: wave stacks not empty at the end";
                     return false;
                 }
-                base += peak;
+                for(size_t qi = 0; qi < lists[w].size(); ++qi)
+                {
+                    int const s = lists[w][qi];
+                    if(root_of[s] != s) S.f_sptr[s] = base + ((depth[s] & 1) ? peak[0] : 0) + rel_off[qi];
+                }
+                base += peak[0] + peak[1];
             }
             {
                 // Cooperative fronts write their update matrix while other wavefronts still gather from the children's,
@@ -869,13 +880,14 @@ namespace pe
             }
             S.arena_doubles = base;
         }
-        // inverse relative maps (cooperative parents only)
+        // inverse relative maps of every parent front
         S.f_inv_off.assign(S.f_child.size(), -1);
         S.f_inv.clear();
+        S.wave_panel_doubles = 1;
         for(int s = 0; s < nf; ++s)
         {
-            if(S.f_kind[s] != 1) continue;
             int const m = S.f_p[s] + S.f_u[s];
+            if(S.f_kind[s] == 0) S.wave_panel_doubles = std::max<long long>(S.wave_panel_doubles, static_cast<long long>(S.f_p[s]) * (m + S.f_u[s]));
             for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
             {
                 int const c = S.f_child[a];

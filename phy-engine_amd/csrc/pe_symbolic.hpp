@@ -16,7 +16,7 @@ namespace pe
 {
     struct SymbolicOptions
     {
-        int nd_leaf{48};          // stop dissecting below this many vertices
+        int nd_leaf{24};          // stop dissecting below this many vertices (measured best on the M10k mesh, profiles/)
         int relax_small{8};       // always merge a last child into its parent while the merged front has <= this many pivots
         double relax_zero_frac{0.30};  // otherwise merge only if the explicit zeros added stay below this fraction of the merged panel
         int max_pivots{48};       // never grow a front beyond this many pivots (chains are split)
@@ -25,7 +25,7 @@ namespace pe
         // wavefront in its own LDS slot; larger fronts are COOPERATIVE: the whole workgroup, pivot panels in LDS
         int wave_m{48};
         int wave_p{24};
-        int absorb_m{32};         // a parent absorbs any child while the merged front order stays <= absorb_m
+        int absorb_m{48};         // a parent absorbs any child while the merged front order stays <= absorb_m (clamped to wave_m)
         int n_waves{8};           // wavefronts per workgroup (static assignment of wave subtrees)
         long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
@@ -56,11 +56,12 @@ namespace pe
         std::vector<long long> f_sptr;          // offset of the u x u update matrix in the stack arena
         long long factor_doubles{};
         long long arena_doubles{};
-        long long work_doubles{};               // largest u*u of a cooperative front (global Schur workspace)
+        long long work_doubles{};               // (unused)
+        long long wave_panel_doubles{};         // largest p*(m+u) of a wave front (LDS doubles of one wavefront's slot)
         std::vector<int> f_kind;                // 0: wave front, 1: cooperative front
         std::vector<int> wave_ptr, wave_list;   // phase 1: fronts of wave w = wave_list[wave_ptr[w] .. wave_ptr[w+1]) in postorder
         std::vector<int> coop_list;             // phase 2: cooperative fronts in postorder
-        // pull-based assembly of cooperative fronts: for child edge e (position in f_child) of a cooperative parent,
+        // pull-based assembly of the Schur blocks: for child edge e (position in f_child),
         // f_inv[f_inv_off[e] + r] = index of parent-local row r among the child's update rows, or -1
         std::vector<long long> f_inv_off;
         std::vector<int> f_inv;

@@ -11,6 +11,7 @@ namespace pe
     struct SerialTeam
     {
         int nw;
+        SerialTeam wave_team(int) const { return SerialTeam{1}; }
         int tid() const { return 0; }
         int size() const { return 1; }
         void sync() const {}
