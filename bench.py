@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- transient hot path on the synthetic 10k-node RC mesh (BASELINE.json metric).
 
-Workload (config C3/C5 of SURVEY.md 8d): M10k-NL = 100x100 RC mesh, R 1k +-5%, C 1p +-5%, 1250 clamp diodes,
-VAC 2 V / 100 MHz through 50 ohm, dt = 1e-10 s.  Every GPU holds `--batch` independent Monte-Carlo instances
+Workload (config C3/C5 of SURVEY.md 8d): M10k-NL = 100x100 RC mesh, R 1k +-5%, C 1p +-5%, 1249 clamp diodes,
+VAC 2 V / 100 MHz through 50 ohm, dt = 1e-10 s.  Every GPU holds `--batch` (default 1024: the whole C5 sweep on one
+GPU; weak scaling keeps 1024 per GPU) independent Monte-Carlo instances
 (seed = global instance index + 1) that share one symbolic analysis; a "step" is one transient time step of every
 instance on that GPU (companion update -> Newton{device eval, MNA gather, multifrontal LU, triangular solves,
 convergence test}).  Weak scaling: per-GPU work is fixed, no data-path collective; the only collective is the
@@ -95,7 +96,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="Monte-Carlo instances per GPU (1024-instance sweep / 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=1024, help="Monte-Carlo instances per GPU (config C5: the 1024-instance sweep; weak scaling keeps it per GPU)")
     ap.add_argument("--mesh", type=int, default=100)
     ap.add_argument("--linear", action="store_true", help="VDC-driven linear variant (no diodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -179,7 +180,7 @@ def main():
             "newton_iters_per_s": iters_total / el,
             "newton_iters_per_step": iters_total / max(1.0, steps_total),
             "config": {"workload": f"M10k{'-NL' if nonlinear else ''}: {W}x{W} RC mesh Monte-Carlo sweep, {B} instances/GPU, dt=1e-10, "
-                                   f"{'1250 diodes + VAC 2V 100MHz' if nonlinear else 'VDC 1V'}",
+                                   f"{'1249 diodes + VAC 2V 100MHz' if nonlinear else 'VDC 1V'}",
                        "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_per_gpu": B,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -189,6 +190,16 @@ def main():
             "stats_checksum": float(np.sum(stats[0])),
             "engine": {k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
         }
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tp):
+            try:
+                tj = json.load(open(tp))
+                if tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W:
+                    # measured offline with rocprofv3 --pmc on this same command (profiles/README.md); bytes per launch
+                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"] * (st["n_launches"] and 1)
+                    line["roofline"]["traffic_note"] = tj.get("note", "")
+            except Exception:
+                pass
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)
