@@ -135,6 +135,8 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
 /* overwrite one parameter column of one device for every instance (values: [batch] if batched else [1]) */
 int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const double* values, int batched);
 
+/* tr_duration / last_step of every instance (circuit.h:161-162), e.g. when a netlist is re-loaded mid-simulation */
+int pe_hip_set_time(pe_hip_engine* h, double t, double last_step);
 int pe_hip_reset(pe_hip_engine* h); /* circult::reset(), circuit.h:446-465: t = 0, x = 0, companion state cleared */
 
 /* one OP / DC / TROP solve (Newton inside), every instance */

@@ -1,0 +1,46 @@
+/* phy_engine_dll_api.h -- the FFI netlist loader + control subset of Phy-Engine's C ABI, exported by libpe_hip.so with
+ * the reference's names, argument meaning and error behaviour (include/phy_engine/dll_api.h:43-47,51-135,143-250;
+ * implementation restated from the behaviour of src/dll_main.cpp:1522-1700, 2254-2359, 2492-2602, 2861-2934).
+ *
+ * Subset (SURVEY.md 8b "FFI loader"): element codes 1 R, 2 C, 3 L, 4 VDC, 5 VAC{Vp, f[Hz], phase[deg]}, 6 IDC,
+ * 13 PN_junction{Is,N,Isr,Nr,Temp,Ibv,Bv,Bv_set,Area}, 54 full_bridge_rectifier, 0 = ground placeholder.  Every
+ * analysis runs on the MI355X through include/pe_hip.h.  Digital / Verilog element codes are rejected (next round).
+ */
+#ifndef PHY_ENGINE_DLL_API_SUBSET_H
+#define PHY_ENGINE_DLL_API_SUBSET_H
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+char const* phy_engine_last_error(void); /* thread-local, valid until the next API call on this thread (dll_api.h:43-47) */
+void phy_engine_clear_error(void);
+
+/* dll_api.h:143-150.  Returns NULL on failure; *vec_pos / *chunk_pos are malloc'd and released by destroy_circuit. */
+void* create_circuit(int* elements, size_t ele_size, int* wires, size_t wires_size, double* properties, size_t** vec_pos, size_t** chunk_pos,
+                     size_t* comp_size);
+void destroy_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos);
+
+int circuit_set_analyze_type(void* circuit_ptr, uint32_t analyze_type_value); /* 0 OP, 1 DC, 4 TR, 5 TROP */
+int circuit_set_tr(void* circuit_ptr, double t_step, double t_stop);
+int circuit_set_temperature(void* circuit_ptr, double temp_c);
+int circuit_set_tnom(void* circuit_ptr, double tnom_c);
+int circuit_set_model_double_by_name(void* circuit_ptr, size_t vec_pos, size_t chunk_pos, char const* name, size_t name_size, double value);
+int circuit_analyze(void* circuit_ptr); /* 0 ok, 1 analysis failed */
+int circuit_digital_clk(void* circuit_ptr);
+
+int circuit_sample_layout(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, size_t* voltage_ord, size_t* current_ord,
+                          size_t* digital_ord);
+int circuit_sample(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, double* voltage, size_t* voltage_ord, double* current,
+                   size_t* current_ord, bool* digital, size_t* digital_ord);
+int circuit_sample_u8(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, double* voltage, size_t* voltage_ord, double* current,
+                      size_t* current_ord, uint8_t* digital, size_t* digital_ord);
+int analyze_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, int* changed_ele, size_t* changed_ind, double* changed_prop,
+                    size_t prop_size, double* voltage, size_t* voltage_ord, double* current, size_t* current_ord, bool* digital, size_t* digital_ord);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -498,6 +498,16 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
     return PE_HIP_OK;
 }
 
+int pe_hip_set_time(pe_hip_engine* h, double t, double last_step)
+{
+    if(!h || !h->loaded) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<double> a(h->hc.batch, t), b(h->hc.batch, last_step);
+    HIPCHK(h, hipMemcpy(h->V.t_now, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->V.last_step, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    return PE_HIP_OK;
+}
+
 int pe_hip_reset(pe_hip_engine* h)
 {
     if(!h || !h->loaded) return PE_HIP_ERR_ARG;

@@ -24,7 +24,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
-    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks",
+    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_set_time",
 ]
 
 

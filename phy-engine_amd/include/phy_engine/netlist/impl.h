@@ -1,0 +1,3 @@
+// path-compatible forwarding header (reference: include/phy_engine/netlist/impl.h)
+#pragma once
+#include <phy_engine/phy_engine_core.h>

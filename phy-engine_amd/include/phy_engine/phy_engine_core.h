@@ -1,0 +1,900 @@
+// phy_engine_core.h -- C++ host layer of the MI355X transient engine, API-compatible with the part of Phy-Engine that
+// sits around the hot path.  Written from scratch (std containers, no Eigen / absl / fast_io); same namespaces, type
+// names, member names and free-function names as the reference so that netlist-building code and tests read the
+// same:
+//
+//   reference                                                        here
+//   include/phy_engine/model/{node,pin,branch}/*.h                    model::node_t / pin / branch (+ views)
+//   include/phy_engine/model/model_refs/{type,variant,concept,base}.h model concept, ADL *_define hooks, model_base
+//   include/phy_engine/netlist/{netlist,operation}.h                  netlist::netlist, add_model/create_node/add_to_node/...
+//   include/phy_engine/circuits/{analyze,environment,MNA/mna}.h       analyze_type, environment, MNA::MNA
+//   include/phy_engine/circuits/circuit.h:60-1528                     struct circult (sic): analyze/prepare/solve/reset
+//
+// What differs by design: `circult::analyze()` never stamps on the host.  A model takes part in the GPU-resident
+// path through ONE additive hook next to its iterate_*_define hooks,
+//       bool gpu_table_define(model_reserve_type_t<M>, M const&, gpu_table_rows&)
+// which describes it as rows of the device tables of include/pe_hip.h.  A netlist containing a model without that hook
+// is rejected by analyze() (returns false, message in circult::last_error) -- there is no CPU numeric path.
+#pragma once
+#include <complex>
+#include <concepts>
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <set>
+#include <string>
+#include <string_view>
+#include <type_traits>
+#include <vector>
+
+#include <fast_io/fast_io_dsal/string_view.h>
+
+#include "../../../include/pe_hip.h"
+
+namespace phy_engine
+{
+    // ---- circuits/analyze.h:7-16
+    enum class analyze_type : ::std::uint_fast32_t
+    {
+        OP = 0,
+        DC,
+        AC,
+        ACOP,
+        TR,
+        TROP
+    };
+
+    // ---- circuits/environment/environment.h:7-22
+    struct environment
+    {
+        double V_eps_max{};
+        double V_epsr_max{};
+        double I_eps_max{};
+        double I_epsr_max{};
+        double charge_eps_max{};
+        double g_min{};
+        double r_open{};
+        double t_TOEF{};
+        double temperature{27.0};
+        double norm_temperature{27.0};
+    };
+
+    namespace analyzer
+    {
+        struct TR
+        {
+            double t_stop{};
+            double t_step{};
+        };
+        struct DC
+        {
+        };
+        struct analyzer_storage_t
+        {
+            TR tr{};
+            DC dc{};
+        };
+    }  // namespace analyzer
+
+    namespace model
+    {
+        struct node_t;
+        struct model_base;
+
+        // ---- model/model_refs/type.h
+        enum class model_type : ::std::size_t
+        {
+            null,
+            invalid,
+            normal
+        };
+        enum class model_device_type : ::std::uint_fast8_t
+        {
+            linear,
+            non_linear,
+            digital
+        };
+
+        // ---- model/node/node.h:25-36 (4-state logic) and :255-306
+        enum class digital_node_statement_t : ::std::uint_fast8_t
+        {
+            false_state = 0,
+            true_state = 1,
+            indeterminate_state = 2,
+            high_impedence_state = 3,
+            L = false_state,
+            H = true_state,
+            X = indeterminate_state,
+            Z = high_impedence_state
+        };
+
+        struct pin
+        {
+            ::fast_io::u8string_view name{};
+            node_t* nodes{};
+            model_base* model{};
+        };
+        struct pin_view
+        {
+            pin* pins{};
+            ::std::size_t size{};
+        };
+        struct branch
+        {
+            ::std::size_t index{};
+            ::std::complex<double> current{};
+        };
+        struct branch_view
+        {
+            branch* branches{};
+            ::std::size_t size{};
+        };
+
+        struct analog_node_t
+        {
+            ::std::complex<double> voltage{};
+        };
+        struct digital_node_t
+        {
+            digital_node_statement_t state{};
+        };
+        union node_information_union
+        {
+            analog_node_t an;
+            digital_node_t dn;
+            node_information_union() : an{} {}
+        };
+
+        struct node_t
+        {
+            node_information_union node_information{};
+            ::std::set<pin*> pins{};
+            ::std::size_t num_of_analog_node{};
+            ::std::size_t node_index{SIZE_MAX};
+
+            node_t() = default;
+            node_t(node_t const& o) : node_information{o.node_information} {}
+            node_t& operator=(node_t const& o)
+            {
+                node_information = o.node_information;
+                pins.clear();
+                return *this;
+            }
+            ~node_t() { clear(); }
+            void destroy() noexcept
+            {
+                pins.clear();
+                num_of_analog_node = 0;
+                node_index = SIZE_MAX;
+            }
+            void clear() noexcept
+            {
+                for(auto* p: pins) p->nodes = nullptr;
+                destroy();
+            }
+        };
+        struct node_view
+        {
+            node_t* nodes{};
+            ::std::size_t size{};
+        };
+
+        // ---- model/model_refs/variant.h
+        enum class variant_type : ::std::uint_fast8_t
+        {
+            invalid,
+            i8,
+            i16,
+            i32,
+            i64,
+            ui8,
+            ui16,
+            ui32,
+            ui64,
+            boolean,
+            f,
+            d,
+            digital
+        };
+        struct variant
+        {
+            union
+            {
+                ::std::int_least64_t i64;
+                ::std::uint_least64_t ui64{};
+                bool boolean;
+                float f;
+                double d;
+                digital_node_statement_t digital;
+            };
+            variant_type type{};
+        };
+    }  // namespace model
+
+    // ---- circuits/MNA/mna.h: kept for source compatibility of user hooks (iterate_*_define(tag, M&, MNA&)); the
+    // GPU-resident path never fills it
+    namespace MNA
+    {
+        struct MNA
+        {
+            ::std::size_t node_size{};
+            ::std::size_t branch_size{};
+            double r_open{1e12};
+        };
+    }  // namespace MNA
+
+    namespace model
+    {
+        // ---- the additive device-table hook ---------------------------------------------------------------------
+        struct gpu_table_row
+        {
+            int kind{};               // pe_hip_kind
+            int pin_a{}, pin_b{};     // indices into the model's pin view
+            int branch{-1};           // index into the model's branch view (L / VDC / VAC), else -1
+            double params[PE_HIP_DIODE_NPARAM]{};
+        };
+        struct gpu_table_rows
+        {
+            gpu_table_row row[4]{};
+            int count{};
+        };
+
+        // ---- model/model_refs/concept.h:23-217 (same hook names and signatures)
+        template <typename mod>
+        struct model_reserve_type_t
+        {
+            static_assert(::std::is_same_v<::std::remove_cvref_t<mod>, mod>);
+            explicit constexpr model_reserve_type_t() noexcept = default;
+        };
+        template <typename mod>
+        inline constexpr model_reserve_type_t<mod> model_reserve_type{};
+
+        namespace defines
+        {
+            template <typename mod>
+            concept can_prepare_foundation = requires(mod&& t) {
+                { prepare_foundation_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_ac = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
+                { iterate_ac_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna, double{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_dc = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
+                { iterate_dc_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_tr = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
+                { iterate_tr_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna, double{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_op = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
+                { iterate_op_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_trop = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
+                { iterate_trop_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_step_changed_tr = requires(mod&& t) {
+                { step_changed_tr_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, double{}, double{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept has_set_attribute = requires(mod&& t) {
+                { set_attribute_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, ::std::size_t{}, variant{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept has_get_attribute = requires(mod&& t) {
+                { get_attribute_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, ::std::size_t{}) } -> ::std::same_as<variant>;
+            };
+            template <typename mod>
+            concept has_full_get_attribute_name = requires(mod&& t) {
+                { get_attribute_name_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, ::std::size_t{}) } -> ::std::same_as<::fast_io::u8string_view>;
+            };
+            template <typename mod>
+            concept has_reduced_get_attribute_name = requires() {
+                { get_attribute_name_define(model_reserve_type<::std::remove_cvref_t<mod>>, ::std::size_t{}) } -> ::std::same_as<::fast_io::u8string_view>;
+            };
+            template <typename mod>
+            concept has_get_attribute_name = has_full_get_attribute_name<mod> || has_reduced_get_attribute_name<mod>;
+            template <typename mod>
+            concept can_generate_pin_view = requires(mod&& t) {
+                { generate_pin_view_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<pin_view>;
+            };
+            template <typename mod>
+            concept can_generate_branch_view = requires(mod&& t) {
+                { generate_branch_view_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<branch_view>;
+            };
+            template <typename mod>
+            concept can_generate_internal_node_view = requires(mod&& t) {
+                { generate_internal_node_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<node_view>;
+            };
+            template <typename mod>
+            concept can_gpu_table = requires(mod const& t, gpu_table_rows& rows) {
+                { gpu_table_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, rows) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_iterate_mna =
+                can_iterate_ac<mod> || can_iterate_dc<mod> || can_iterate_op<mod> || can_iterate_tr<mod> || can_iterate_trop<mod> || can_gpu_table<mod>;
+            template <typename mod>
+            concept is_valid_digital_model = false;  // digital event models: next round
+        }  // namespace defines
+
+        namespace details
+        {
+            template <typename mod, typename = void>
+            struct model_check : ::std::false_type
+            {
+            };
+            template <typename mod>
+            struct model_check<mod,
+                               ::std::void_t<decltype(::std::remove_cvref_t<mod>::model_name), decltype(::std::remove_cvref_t<mod>::device_type),
+                                             decltype(::std::remove_cvref_t<mod>::identification_name)>> :
+                ::std::bool_constant<::std::is_same_v<::std::remove_cvref_t<decltype(::std::remove_cvref_t<mod>::model_name)>, ::fast_io::u8string_view> &&
+                                     ::std::is_same_v<::std::remove_cvref_t<decltype(::std::remove_cvref_t<mod>::device_type)>, model_device_type> &&
+                                     ::std::is_same_v<::std::remove_cvref_t<decltype(::std::remove_cvref_t<mod>::identification_name)>, ::fast_io::u8string_view>>
+            {
+            };
+
+            // type-erased interface (model/model_refs/base.h:21-62), reduced to what the resident path consults
+            struct model_base_impl
+            {
+                virtual ~model_base_impl() = default;
+                virtual model_base_impl* clone() const = 0;
+                virtual bool set_attribute(::std::size_t index, variant vi) noexcept = 0;
+                virtual variant get_attribute(::std::size_t index) noexcept = 0;
+                virtual ::fast_io::u8string_view get_attribute_name(::std::size_t index) noexcept = 0;
+                virtual pin_view generate_pin_view() noexcept = 0;
+                virtual branch_view generate_branch_view() noexcept = 0;
+                virtual node_view generate_internal_node_view() noexcept = 0;
+                virtual ::fast_io::u8string_view get_model_name() noexcept = 0;
+                virtual ::fast_io::u8string_view get_identification_name() noexcept = 0;
+                virtual model_device_type get_device_type() noexcept = 0;
+                virtual bool has_gpu_table() noexcept = 0;
+                virtual bool gpu_table(gpu_table_rows& rows) noexcept = 0;
+            };
+
+            template <typename mod>
+            struct model_derv_impl final : model_base_impl
+            {
+                using T = ::std::remove_cvref_t<mod>;
+                T m;
+                explicit model_derv_impl(T const& in) : m{in} {}
+                explicit model_derv_impl(T&& in) : m{::std::move(in)} {}
+                model_base_impl* clone() const override { return new model_derv_impl<T>{m}; }
+                bool set_attribute(::std::size_t index, variant vi) noexcept override
+                {
+                    if constexpr(defines::has_set_attribute<T>) return set_attribute_define(model_reserve_type<T>, m, index, vi);
+                    else
+                        return false;
+                }
+                variant get_attribute(::std::size_t index) noexcept override
+                {
+                    if constexpr(defines::has_get_attribute<T>) return get_attribute_define(model_reserve_type<T>, m, index);
+                    else
+                        return {};
+                }
+                ::fast_io::u8string_view get_attribute_name(::std::size_t index) noexcept override
+                {
+                    if constexpr(defines::has_full_get_attribute_name<T>) return get_attribute_name_define(model_reserve_type<T>, m, index);
+                    else if constexpr(defines::has_reduced_get_attribute_name<T>)
+                        return get_attribute_name_define(model_reserve_type<T>, index);
+                    else
+                        return {};
+                }
+                pin_view generate_pin_view() noexcept override { return generate_pin_view_define(model_reserve_type<T>, m); }
+                branch_view generate_branch_view() noexcept override
+                {
+                    if constexpr(defines::can_generate_branch_view<T>) return generate_branch_view_define(model_reserve_type<T>, m);
+                    else
+                        return {};
+                }
+                node_view generate_internal_node_view() noexcept override
+                {
+                    if constexpr(defines::can_generate_internal_node_view<T>) return generate_internal_node_define(model_reserve_type<T>, m);
+                    else
+                        return {};
+                }
+                ::fast_io::u8string_view get_model_name() noexcept override { return T::model_name; }
+                ::fast_io::u8string_view get_identification_name() noexcept override { return T::identification_name; }
+                model_device_type get_device_type() noexcept override { return T::device_type; }
+                bool has_gpu_table() noexcept override { return defines::can_gpu_table<T>; }
+                bool gpu_table(gpu_table_rows& rows) noexcept override
+                {
+                    if constexpr(defines::can_gpu_table<T>) return gpu_table_define(model_reserve_type<T>, m, rows);
+                    else
+                        return false;
+                }
+            };
+        }  // namespace details
+
+        template <typename mod>
+        concept model = details::model_check<mod>::value;
+
+        // ---- owning handle (model/model_refs/base.h:534-827)
+        struct model_base
+        {
+            model_type type{};
+            details::model_base_impl* ptr{};
+            ::std::size_t identification{};
+            ::std::u8string name{};
+            ::std::u8string describe{};
+            bool has_init{};
+
+            model_base() = default;
+            template <typename mod>
+                requires (model<mod> && !::std::is_same_v<::std::remove_cvref_t<mod>, model_base>)
+            model_base(mod&& m) : type{model_type::normal}, ptr{new details::model_derv_impl<::std::remove_cvref_t<mod>>{::std::forward<mod>(m)}}
+            {
+            }
+            model_base(model_base const& o) : type{o.type}, ptr{o.ptr ? o.ptr->clone() : nullptr}, identification{o.identification}, name{o.name}, describe{o.describe}, has_init{o.has_init}
+            {
+                detach_pins();
+            }
+            model_base(model_base&& o) noexcept : type{o.type}, ptr{o.ptr}, identification{o.identification}, name{::std::move(o.name)}, describe{::std::move(o.describe)}, has_init{o.has_init}
+            {
+                o.ptr = nullptr;
+                o.type = model_type::null;
+            }
+            model_base& operator=(model_base const& o)
+            {
+                if(this == &o) return *this;
+                delete ptr;
+                type = o.type;
+                ptr = o.ptr ? o.ptr->clone() : nullptr;
+                identification = o.identification;
+                name = o.name;
+                describe = o.describe;
+                has_init = o.has_init;
+                detach_pins();
+                return *this;
+            }
+            ~model_base() { clear(); }
+            void clear() noexcept
+            {
+                if(ptr)
+                {
+                    auto pv = ptr->generate_pin_view();
+                    for(::std::size_t i = 0; i < pv.size; ++i)
+                        if(pv.pins[i].nodes)
+                        {
+                            pv.pins[i].nodes->pins.erase(pv.pins + i);
+                            if(ptr->get_device_type() != model_device_type::digital && pv.pins[i].nodes->num_of_analog_node) --pv.pins[i].nodes->num_of_analog_node;
+                            pv.pins[i].nodes = nullptr;
+                        }
+                    delete ptr;
+                    ptr = nullptr;
+                }
+                type = model_type::null;
+            }
+
+        private:
+            void detach_pins() noexcept
+            {
+                if(!ptr) return;
+                auto pv = ptr->generate_pin_view();
+                for(::std::size_t i = 0; i < pv.size; ++i) pv.pins[i].nodes = nullptr;
+            }
+        };
+    }  // namespace model
+
+    // ---- netlist/netlist.h + operation.h: chunked arenas (addresses of models and nodes are stable), same operations
+    namespace netlist
+    {
+        namespace details
+        {
+            template <typename T>
+            struct block
+            {
+                inline static constexpr ::std::size_t chunk_size{4096};
+                inline static constexpr ::std::size_t chunk_module_size{chunk_size / sizeof(T) > 0 ? chunk_size / sizeof(T) : 1};
+                T* begin{};
+                T* curr{};
+                ::std::size_t num_of_null_model{};
+                block() : begin{static_cast<T*>(::operator new(sizeof(T) * chunk_module_size))}, curr{begin} {}
+                block(block&& o) noexcept : begin{o.begin}, curr{o.curr}, num_of_null_model{o.num_of_null_model} { o.begin = o.curr = nullptr; }
+                block(block const&) = delete;
+                ~block()
+                {
+                    for(T* p = begin; p != curr; ++p) p->~T();
+                    ::operator delete(begin);
+                }
+                ::std::size_t size() const noexcept { return static_cast<::std::size_t>(curr - begin); }
+            };
+            using netlist_model_base_block = block<::phy_engine::model::model_base>;
+            using netlist_node_block = block<::phy_engine::model::node_t>;
+        }  // namespace details
+
+        struct netlist
+        {
+            ::std::vector<details::netlist_model_base_block> models{};
+            ::std::vector<details::netlist_node_block> nodes{};
+            ::phy_engine::model::node_t ground_node{};
+            netlist() = default;
+            netlist(netlist const&) = delete;
+            netlist& operator=(netlist const&) = delete;
+        };
+
+        struct model_pos
+        {
+            ::std::size_t vec_pos{};
+            ::std::size_t chunk_pos{};
+        };
+        struct add_model_retstr
+        {
+            ::phy_engine::model::model_base* mod{};
+            model_pos mod_pos{};
+        };
+
+        inline ::phy_engine::model::node_t& get_ground_node(netlist& nl) noexcept { return nl.ground_node; }
+
+        // netlist/operation.h:46-89
+        template <typename mod>
+            requires (::phy_engine::model::model<mod> && ::phy_engine::model::defines::can_generate_pin_view<mod> &&
+                      (::phy_engine::model::defines::can_iterate_mna<mod> || ::phy_engine::model::defines::is_valid_digital_model<mod>))
+        inline add_model_retstr add_model(netlist& nl, mod&& m)
+        {
+            if(nl.models.empty() || nl.models.back().size() == details::netlist_model_base_block::chunk_module_size) nl.models.emplace_back();
+            auto& blk = nl.models.back();
+            ::new(blk.curr)::phy_engine::model::model_base{::std::forward<mod>(m)};
+            add_model_retstr r{blk.curr, {blk.size(), nl.models.size() - 1}};
+            ++blk.curr;
+            return r;
+        }
+
+        inline ::phy_engine::model::model_base* get_model(netlist const& nl, ::std::size_t vec_pos, ::std::size_t chunk_pos) noexcept
+        {
+            if(chunk_pos >= nl.models.size()) return nullptr;
+            auto const& blk = nl.models[chunk_pos];
+            if(vec_pos >= blk.size()) return nullptr;
+            return blk.begin + vec_pos;
+        }
+        inline ::phy_engine::model::model_base* get_model(netlist const& nl, model_pos pos) noexcept { return get_model(nl, pos.vec_pos, pos.chunk_pos); }
+
+        // netlist/operation.h:91-133: the last model of a chunk is destroyed, others become null placeholders
+        inline bool delete_model(netlist& nl, ::std::size_t vec_pos, ::std::size_t chunk_pos) noexcept
+        {
+            if(chunk_pos >= nl.models.size()) return false;
+            auto& blk = nl.models[chunk_pos];
+            auto* i = blk.begin + vec_pos;
+            if(i >= blk.curr) return false;
+            if(i == blk.curr - 1)
+            {
+                bool const was_null = i->type == ::phy_engine::model::model_type::null;
+                if(was_null) --blk.num_of_null_model;
+                i->~model_base();
+                --blk.curr;
+                return !was_null;
+            }
+            if(i->type == ::phy_engine::model::model_type::null) return false;
+            ++blk.num_of_null_model;
+            i->clear();
+            return true;
+        }
+        inline bool delete_model(netlist& nl, model_pos pos) noexcept { return delete_model(nl, pos.vec_pos, pos.chunk_pos); }
+
+        inline ::phy_engine::model::node_t& create_node(netlist& nl)
+        {
+            if(nl.nodes.empty() || nl.nodes.back().size() == details::netlist_node_block::chunk_module_size) nl.nodes.emplace_back();
+            auto& blk = nl.nodes.back();
+            ::new(blk.curr)::phy_engine::model::node_t{};
+            return *(blk.curr++);
+        }
+
+        // netlist/operation.h:167-205
+        inline bool add_to_node([[maybe_unused]] netlist const& nl, ::phy_engine::model::model_base& model, ::std::size_t n1, ::phy_engine::model::node_t& node) noexcept
+        {
+            auto pw = model.ptr->generate_pin_view();
+            if(n1 >= pw.size) return false;
+            auto& p = pw.pins[n1];
+            p.nodes = &node;
+            node.pins.insert(&p);
+            if(model.ptr->get_device_type() != ::phy_engine::model::model_device_type::digital) ++node.num_of_analog_node;
+            return true;
+        }
+        inline bool add_to_node(netlist& nl, model_pos mp, ::std::size_t n1, ::phy_engine::model::node_t& node) noexcept
+        {
+            auto* m = get_model(nl, mp);
+            return m ? add_to_node(nl, *m, n1, node) : false;
+        }
+        inline bool remove_from_node([[maybe_unused]] netlist const& nl, ::phy_engine::model::model_base& model, ::std::size_t n1, ::phy_engine::model::node_t& node) noexcept
+        {
+            auto pw = model.ptr->generate_pin_view();
+            if(n1 >= pw.size) return false;
+            auto& p = pw.pins[n1];
+            p.nodes = nullptr;
+            node.pins.erase(&p);
+            if(model.ptr->get_device_type() != ::phy_engine::model::model_device_type::digital) --node.num_of_analog_node;
+            return true;
+        }
+        inline void delete_node([[maybe_unused]] netlist const& nl, ::phy_engine::model::node_t& node) noexcept { node.clear(); }
+
+        // netlist/operation.h:251-259 -- including its quirk: the survivor's num_of_analog_node is NOT increased
+        // (SURVEY.md appendix A.7); analog indexing below therefore also accepts nodes that hold analog pins.
+        inline void merge_node([[maybe_unused]] netlist const& nl, ::phy_engine::model::node_t& node, ::phy_engine::model::node_t& other_node) noexcept
+        {
+            for(auto* i: other_node.pins)
+            {
+                node.pins.insert(i);
+                i->nodes = &node;
+            }
+            other_node.destroy();
+        }
+
+        template <bool check = false>
+        inline ::std::size_t get_num_of_model(netlist const& nl) noexcept
+        {
+            ::std::size_t res{};
+            for(auto const& b: nl.models)
+                for(auto* p = b.begin; p != b.curr; ++p)
+                    if(!check || p->type != ::phy_engine::model::model_type::null) ++res;
+            return res;
+        }
+    }  // namespace netlist
+
+    // ---- circuits/circuit.h:60-1528
+    struct circult
+    {
+        environment env{};
+        ::phy_engine::netlist::netlist nl{};
+        analyze_type at{};
+        ::phy_engine::analyzer::analyzer_storage_t analyzer_setting{};
+
+        bool has_prepare{};
+        ::std::size_t node_counter{};
+        ::std::size_t branch_counter{};
+        ::std::vector<::phy_engine::model::node_t*> size_t_to_node_p{};
+        ::std::vector<::phy_engine::model::branch*> size_t_to_branch_p{};
+        double tr_duration{};
+        double last_step{};
+        ::std::string last_error{};
+        pe_hip_run_stats last_stats{};
+
+        circult() = default;
+        circult(circult const&) = delete;
+        circult& operator=(circult const&) = delete;
+        ~circult()
+        {
+            if(gpu_) pe_hip_destroy(gpu_);
+        }
+
+        environment& get_environment() noexcept { return env; }
+        ::phy_engine::netlist::netlist& get_netlist() noexcept { return nl; }
+        void set_analyze_type(analyze_type other) noexcept { at = other; }
+        ::phy_engine::analyzer::analyzer_storage_t& get_analyze_setting() noexcept { return analyzer_setting; }
+        pe_hip_engine* gpu_engine() noexcept { return gpu_; }
+
+        // circuit.h:179-296
+        bool analyze() noexcept
+        {
+            switch(at)
+            {
+                case analyze_type::OP: [[fallthrough]];
+                case analyze_type::DC:
+                    if(!prepare()) return false;
+                    return solve();
+                case analyze_type::TR: return run_tr(false);
+                case analyze_type::TROP: return run_tr(true);
+                default: last_error = "AC / ACOP analysis is outside the MI355X hot path (SURVEY.md 8f)"; return false;
+            }
+        }
+
+        // circuit.h:446-465
+        void reset() noexcept
+        {
+            tr_duration = 0.0;
+            last_step = 0.0;
+            for(auto* n: size_t_to_node_p) n->node_information.an.voltage = {};
+            for(auto* b: size_t_to_branch_p) b->current = {};
+            node_counter = branch_counter = 0;
+            size_t_to_node_p.clear();
+            size_t_to_branch_p.clear();
+            has_prepare = false;
+            if(gpu_ && loaded_) (void)pe_hip_reset(gpu_);
+        }
+
+        // circuit.h:468-890: index nodes / branches and (re)build the device tables; loads the GPU engine when the
+        // netlist (topology or parameters) differs from what is resident
+        bool prepare() noexcept
+        {
+            using namespace ::phy_engine::model;
+            node_counter = 0;
+            size_t_to_node_p.clear();
+            for(auto& blk: nl.nodes)
+                for(auto* c = blk.begin; c != blk.curr; ++c)
+                {
+                    bool analog = c->num_of_analog_node != 0;
+                    if(!analog)  // merge_node quirk: the survivor may hold analog pins without counting them
+                        for(auto* p: c->pins)
+                            if(p->model && p->model->ptr && p->model->ptr->get_device_type() != model_device_type::digital) analog = true;
+                    if(!analog) continue;
+                    size_t_to_node_p.push_back(c);
+                    c->node_index = node_counter++;
+                }
+            nl.ground_node.node_index = SIZE_MAX;
+            branch_counter = 0;
+            size_t_to_branch_p.clear();
+
+            tables_ next{};
+            for(auto& blk: nl.models)
+                for(auto* c = blk.begin; c != blk.curr; ++c)
+                {
+                    if(c->type != model_type::normal) continue;
+                    auto const pv = c->ptr->generate_pin_view();
+                    for(::std::size_t i = 0; i < pv.size; ++i) pv.pins[i].model = c;
+                    auto const bv = c->ptr->generate_branch_view();
+                    ::std::size_t const branch0 = branch_counter;
+                    for(::std::size_t i = 0; i < bv.size; ++i)
+                    {
+                        size_t_to_branch_p.push_back(bv.branches + i);
+                        bv.branches[i].index = branch_counter++;
+                    }
+                    gpu_table_rows rows{};
+                    if(!c->ptr->has_gpu_table() || !c->ptr->gpu_table(rows))
+                    {
+                        auto const nm = c->ptr->get_model_name();
+                        last_error = "model '" + ::std::string(reinterpret_cast<char const*>(nm.data()), nm.size()) +
+                                     "' has no gpu_table_define hook: the MI355X engine has no host stamping path";
+                        return false;
+                    }
+                    for(int r = 0; r < rows.count; ++r)
+                    {
+                        auto const& row = rows.row[r];
+                        auto node_id = [&](int pin) -> int
+                        {
+                            auto* n = pv.pins[pin].nodes;
+                            if(!n) return -1;
+                            return n == &nl.ground_node ? 0 : static_cast<int>(n->node_index) + 1;
+                        };
+                        auto& t = next.kind[row.kind];
+                        t.nodes.push_back(node_id(row.pin_a));
+                        t.nodes.push_back(node_id(row.pin_b));
+                        if(row.branch >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch);
+                        int const ncol = row.kind == PE_HIP_VAC ? 3 : (row.kind == PE_HIP_DIODE ? PE_HIP_DIODE_NPARAM : 1);
+                        for(int q = 0; q < ncol; ++q) t.params.push_back(row.params[q]);
+                    }
+                }
+            next.n_nodes = static_cast<int>(node_counter);
+            next.n_branches = static_cast<int>(branch_counter);
+
+            if(!gpu_)
+            {
+                if(pe_hip_create(0, &gpu_) != PE_HIP_OK)
+                {
+                    last_error = pe_hip_last_error(nullptr);
+                    return false;
+                }
+            }
+            pe_hip_options o{};
+            o.v_abstol = env.V_eps_max;
+            o.v_reltol = env.V_epsr_max;
+            o.i_abstol = env.I_eps_max;
+            o.i_reltol = env.I_epsr_max;
+            o.g_min = env.g_min;
+            o.refactor_every_solve = 1;
+            if(pe_hip_set_options(gpu_, &o) != PE_HIP_OK) return gpu_fail();
+
+            if(!loaded_ || !next.same_topology(resident_))
+            {
+                ::std::vector<pe_hip_device_table> tabs;
+                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                {
+                    auto& t = next.kind[k];
+                    if(t.nodes.empty()) continue;
+                    tabs.push_back({k, static_cast<int>(t.nodes.size() / 2), t.nodes.data(), t.branch.empty() ? nullptr : t.branch.data(), t.params.data(), 0});
+                }
+                if(pe_hip_load_circuit(gpu_, next.n_nodes, next.n_branches, 1, static_cast<int>(tabs.size()), tabs.data()) != PE_HIP_OK) return gpu_fail();
+                loaded_ = true;
+                // resume from the state the netlist carries (circult keeps node voltages / branch currents in the netlist)
+                ::std::vector<double> x(node_counter + branch_counter, 0.0);
+                for(auto* n: size_t_to_node_p) x[n->node_index] = n->node_information.an.voltage.real();
+                for(auto* b: size_t_to_branch_p) x[node_counter + b->index] = b->current.real();
+                if(!x.empty() && pe_hip_set_solution(gpu_, 0, 1, x.data()) != PE_HIP_OK) return gpu_fail();
+                if(pe_hip_set_time(gpu_, tr_duration, last_step) != PE_HIP_OK) return gpu_fail();
+            }
+            else
+            {
+                // same topology: push changed parameters only
+                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                {
+                    auto const& a = next.kind[k].params;
+                    auto const& b = resident_.kind[k].params;
+                    int const ncol = k == PE_HIP_VAC ? 3 : (k == PE_HIP_DIODE ? PE_HIP_DIODE_NPARAM : 1);
+                    for(::std::size_t i = 0; i < a.size(); ++i)
+                        if(a[i] != b[i])
+                            if(pe_hip_update_param(gpu_, k, static_cast<int>(i / ncol), static_cast<int>(i % ncol), &a[i], 0) != PE_HIP_OK) return gpu_fail();
+                }
+            }
+            resident_ = ::std::move(next);
+            has_prepare = true;
+            return true;
+        }
+
+        // circuit.h:892-985 (+ solve_once): one OP / DC / TROP point, Newton on the device
+        bool solve() noexcept
+        {
+            if(!gpu_ || !loaded_) return false;
+            int const mode = at == analyze_type::OP ? PE_HIP_MODE_OP : (at == analyze_type::TROP ? PE_HIP_MODE_TROP : PE_HIP_MODE_DC);
+            int const rc = node_counter + branch_counter == 0 ? PE_HIP_OK : pe_hip_analyze_dc(gpu_, mode, &last_stats);
+            scatter();
+            if(rc != PE_HIP_OK) return gpu_fail();
+            return true;
+        }
+
+    private:
+        struct table_
+        {
+            ::std::vector<int> nodes, branch;
+            ::std::vector<double> params;
+        };
+        struct tables_
+        {
+            int n_nodes{}, n_branches{};
+            table_ kind[PE_HIP_DIODE + 1]{};
+            bool same_topology(tables_ const& o) const
+            {
+                if(n_nodes != o.n_nodes || n_branches != o.n_branches) return false;
+                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                    if(kind[k].nodes != o.kind[k].nodes || kind[k].branch != o.kind[k].branch || kind[k].params.size() != o.kind[k].params.size()) return false;
+                return true;
+            }
+        };
+
+        pe_hip_engine* gpu_{};
+        bool loaded_{};
+        tables_ resident_{};
+
+        bool gpu_fail() noexcept
+        {
+            last_error = pe_hip_last_error(gpu_);
+            return false;
+        }
+
+        // circuit.h:1521-1523
+        void scatter() noexcept
+        {
+            ::std::size_t const rows = node_counter + branch_counter;
+            if(!rows) return;
+            ::std::vector<double> x(rows);
+            if(pe_hip_get_solution(gpu_, 0, 1, x.data()) != PE_HIP_OK) return;
+            for(auto* n: size_t_to_node_p) n->node_information.an.voltage = x[n->node_index];
+            nl.ground_node.node_information.an.voltage = {};
+            for(auto* b: size_t_to_branch_p) b->current = x[node_counter + b->index];
+        }
+
+        // circuit.h:233-289: the step count is what the reference's floating-point loop bound yields
+        bool run_tr(bool trop) noexcept
+        {
+            double const dt = analyzer_setting.tr.t_step;
+            if(dt <= 0.0) return false;
+            double const t_stop = analyzer_setting.tr.t_stop;
+            if(!prepare()) return false;
+            if(trop)
+            {
+                auto const saved = at;
+                at = analyze_type::TROP;
+                bool const ok = solve();
+                at = saved;
+                if(!ok) return false;
+            }
+            int n = 0;
+            {
+                double t = tr_duration;
+                double const end_time = tr_duration + t_stop;
+                for(; t < end_time; t = t + dt) ++n;
+            }
+            int const rc = (n == 0 || node_counter + branch_counter == 0) ? PE_HIP_OK : pe_hip_analyze_tr(gpu_, dt, n, &last_stats);
+            scatter();
+            double t_now = tr_duration;
+            long long steps = 0;
+            if(node_counter + branch_counter != 0)
+                (void)pe_hip_get_instance_state(gpu_, 0, 1, nullptr, &steps, nullptr, &t_now);
+            else
+                for(int i = 0; i < n; ++i) t_now = t_now + dt;
+            tr_duration = t_now;  // on failure the engine has rolled the failing step back (circuit.h:249-253)
+            last_step = dt;
+            if(rc != PE_HIP_OK) return gpu_fail();
+            return true;
+        }
+    };
+}  // namespace phy_engine

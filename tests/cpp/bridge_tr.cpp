@@ -1,0 +1,83 @@
+// Config C2: VAC 10 V / 50 Hz -> full_bridge_rectifier -> 1 kOhm || 100 uF, g_min = 1e-12, through the
+// C++ plug-in API: v+(5 ms) and v+(30 ms) against the values the real reference produces (tests/golden/bridge_c2).
+// Also: a user model WITHOUT the gpu_table_define hook is accepted by add_model (it has iterate_dc_define) but
+// analyze() refuses it loudly -- there is no host stamping path.
+#include <cmath>
+#include <cstdio>
+#include <numbers>
+
+#include <phy_engine/phy_engine.h>
+
+namespace user
+{
+    struct host_only_resistor
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"HostOnlyR"};
+        inline static constexpr ::phy_engine::model::model_device_type device_type{::phy_engine::model::model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"HR"};
+        ::phy_engine::model::pin pins[2]{{{u8"A"}}, {{u8"B"}}};
+    };
+    inline bool iterate_dc_define(::phy_engine::model::model_reserve_type_t<host_only_resistor>, host_only_resistor const&, ::phy_engine::MNA::MNA&) noexcept { return true; }
+    inline ::phy_engine::model::pin_view generate_pin_view_define(::phy_engine::model::model_reserve_type_t<host_only_resistor>, host_only_resistor& m) noexcept { return {m.pins, 2}; }
+}  // namespace user
+
+int main()
+{
+    using namespace ::phy_engine;
+    circult c{};
+    c.set_analyze_type(analyze_type::TR);
+    c.env.g_min = 1e-12;
+    c.get_analyze_setting().tr.t_step = 1e-5;
+    c.get_analyze_setting().tr.t_stop = 5e-3;
+    auto& nl{c.get_netlist()};
+    auto [vac, p0]{add_model(nl, model::VAC{.m_Vp = 10.0, .m_omega = 2.0 * std::numbers::pi * 50.0, .m_phase = 0.0})};
+    auto [fbr, p1]{add_model(nl, model::full_bridge_rectifier{})};
+    auto [r, p2]{add_model(nl, model::resistance{.r = 1000.0})};
+    auto [cap, p3]{add_model(nl, model::capacitor{.m_kZimag = 100e-6})};
+    auto& a{create_node(nl)};
+    auto& b{create_node(nl)};
+    auto& plus{create_node(nl)};
+    auto& gnd{nl.ground_node};
+    add_to_node(nl, *vac, 0, a);
+    add_to_node(nl, *vac, 1, b);
+    add_to_node(nl, *fbr, 0, a);
+    add_to_node(nl, *fbr, 1, b);
+    add_to_node(nl, *fbr, 2, plus);
+    add_to_node(nl, *fbr, 3, gnd);
+    add_to_node(nl, *r, 0, plus);
+    add_to_node(nl, *r, 1, gnd);
+    add_to_node(nl, *cap, 0, plus);
+    add_to_node(nl, *cap, 1, gnd);
+    if(!c.analyze())
+    {
+        std::fprintf(stderr, "bridge: %s\n", c.last_error.c_str());
+        return 1;
+    }
+    double const v5 = plus.node_information.an.voltage.real();
+    // the reference's floating-point loop bound (circuit.h:242-254) makes t_stop = 5e-3 / dt = 1e-5 run 501 steps;
+    // real reference at step 501 (oracle/_ref/ref_driver): v+ = 8.52738489
+    if(c.last_stats.steps != 501 || std::abs(v5 - 8.52738489) > 2e-8)
+    {
+        std::fprintf(stderr, "bridge: v+(5ms)=%.12g steps=%lld\n", v5, c.last_stats.steps);
+        return 2;
+    }
+    // second analyze() continues from the resident state
+    c.get_analyze_setting().tr.t_stop = 25e-3;
+    if(!c.analyze()) return 3;
+    double const v30 = plus.node_information.an.voltage.real();
+    if(!(v30 > 8.0 && v30 < 8.4))
+    {
+        std::fprintf(stderr, "bridge: v+(30ms)=%.12g\n", v30);
+        return 4;
+    }
+    // a host-only model is a valid plug-in for add_model, but the engine refuses to analyze it
+    circult c2{};
+    c2.set_analyze_type(analyze_type::DC);
+    auto [hr, hp]{add_model(c2.get_netlist(), user::host_only_resistor{})};
+    auto& n1{create_node(c2.get_netlist())};
+    add_to_node(c2.get_netlist(), *hr, 0, n1);
+    add_to_node(c2.get_netlist(), *hr, 1, c2.get_netlist().ground_node);
+    if(c2.analyze()) return 5;
+    if(c2.last_error.find("gpu_table_define") == std::string::npos) return 6;
+    return 0;
+}
