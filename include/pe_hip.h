@@ -129,7 +129,8 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* opt);
 int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out);
 
 /* digital_out of circult (circuit.h:102,509,1015-1022): ideal sources occupying the FIRST `count` branches.
- * The count is fixed at load time through n_branches accounting: pass the drives before pe_hip_load_circuit(). */
+ * Pass the drives before pe_hip_load_circuit() (they are part of the branch numbering).  On a loaded engine the same
+ * drive set with new voltages updates in place; a different set invalidates the resident circuit (reload it). */
 int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, const double* volt);
 
 /* overwrite one parameter column of one device for every instance (values: [batch] if batched else [1]) */

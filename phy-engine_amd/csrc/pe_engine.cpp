@@ -368,17 +368,21 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
     if(!h || count < 0 || (count > 0 && (!node || !volt))) return PE_HIP_ERR_ARG;
     if(h->loaded)
     {
-        // after load only the voltages may change (same drives, same order)
-        if(count != h->hc.n_drives) return fail(h, PE_HIP_ERR_ARG, "digital drive set changed: reload the circuit");
-        for(int k = 0; k < count; ++k)
-            if((node[k] == 0 ? -1 : node[k] - 1) != h->hc.drv_node[k]) return fail(h, PE_HIP_ERR_ARG, "digital drive set changed: reload the circuit");
-        HIPCHK(h, hipSetDevice(h->device));
-        for(int k = 0; k < count; ++k)
+        // same drives in the same order: only the voltages change; a different set needs pe_hip_load_circuit again
+        bool same = count == h->hc.n_drives;
+        for(int k = 0; k < count && same; ++k) same = (node[k] == 0 ? -1 : node[k] - 1) == h->hc.drv_node[k];
+        if(same)
         {
-            std::vector<double> col(h->hc.batch, volt[k]);
-            HIPCHK(h, hipMemcpy2D(h->V.dv + h->hc.dv_drv + k, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double),
-                                  h->hc.batch, hipMemcpyHostToDevice));
+            HIPCHK(h, hipSetDevice(h->device));
+            for(int k = 0; k < count; ++k)
+            {
+                std::vector<double> col(h->hc.batch, volt[k]);
+                HIPCHK(h, hipMemcpy2D(h->V.dv + h->hc.dv_drv + k, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double),
+                                      h->hc.batch, hipMemcpyHostToDevice));
+            }
         }
+        else
+            h->loaded = false;  // the resident circuit no longer matches: every compute entry point refuses until reloaded
     }
     h->drv_node.assign(node, node + count);
     h->drv_volt.assign(volt, volt + count);

@@ -179,6 +179,42 @@ namespace phy_engine
             ::std::size_t size{};
         };
 
+        // ---- model/node/node.h:18-23
+        enum class digital_update_method_t : ::std::uint_fast8_t
+        {
+            update_table = 0x00,
+            before_all_clk = 0x01,
+            after_all_clk = 0x02,
+        };
+
+        // 4-state algebra (model/node/node.h:78-230): L dominates AND, H dominates OR, X / Z otherwise unknown
+        inline constexpr digital_node_statement_t operator&(digital_node_statement_t a, digital_node_statement_t b) noexcept
+        {
+            using s = digital_node_statement_t;
+            if(a == s::false_state || b == s::false_state) return s::false_state;
+            if(a == s::true_state && b == s::true_state) return s::true_state;
+            return s::indeterminate_state;
+        }
+        inline constexpr digital_node_statement_t operator|(digital_node_statement_t a, digital_node_statement_t b) noexcept
+        {
+            using s = digital_node_statement_t;
+            if(a == s::true_state || b == s::true_state) return s::true_state;
+            if(a == s::false_state && b == s::false_state) return s::false_state;
+            return s::indeterminate_state;
+        }
+        inline constexpr digital_node_statement_t operator~(digital_node_statement_t a) noexcept
+        {
+            using s = digital_node_statement_t;
+            return a == s::false_state ? s::true_state : (a == s::true_state ? s::false_state : s::indeterminate_state);
+        }
+        inline constexpr digital_node_statement_t operator^(digital_node_statement_t a, digital_node_statement_t b) noexcept
+        {
+            using s = digital_node_statement_t;
+            bool const da = a == s::false_state || a == s::true_state, db = b == s::false_state || b == s::true_state;
+            if(!da || !db) return s::indeterminate_state;
+            return (a == s::true_state) != (b == s::true_state) ? s::true_state : s::false_state;
+        }
+
         // ---- model/model_refs/variant.h
         enum class variant_type : ::std::uint_fast8_t
         {
@@ -222,6 +258,21 @@ namespace phy_engine
             double r_open{1e12};
         };
     }  // namespace MNA
+
+    // ---- circuits/digital/update_table.h:8-27
+    namespace digital
+    {
+        struct digital_node_update_table
+        {
+            ::std::set<::phy_engine::model::node_t*> always_tables{};  // hybrid nodes: re-evaluated on every tick
+            ::std::set<::phy_engine::model::node_t*> tables{};         // pending nodes of the current tick
+        };
+        struct need_operate_analog_node_t
+        {
+            double voltage{};
+            ::phy_engine::model::node_t* need_to_operate_analog_node{};
+        };
+    }  // namespace digital
 
     namespace model
     {
@@ -317,7 +368,15 @@ namespace phy_engine
             concept can_iterate_mna =
                 can_iterate_ac<mod> || can_iterate_dc<mod> || can_iterate_op<mod> || can_iterate_tr<mod> || can_iterate_trop<mod> || can_gpu_table<mod>;
             template <typename mod>
-            concept is_valid_digital_model = false;  // digital event models: next round
+            concept can_update_digital_clk = requires(mod&& t, ::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) {
+                {
+                    update_digital_clk_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, table, tr_duration, method)
+                } -> ::std::same_as<::phy_engine::digital::need_operate_analog_node_t>;
+            };
+            template <typename mod>
+            concept has_digital_update_method = ::std::same_as<::std::remove_cvref_t<decltype(::std::remove_cvref_t<mod>::digital_update_method)>, digital_update_method_t>;
+            template <typename mod>
+            concept is_valid_digital_model = ::std::remove_cvref_t<mod>::device_type == model_device_type::digital && can_update_digital_clk<mod> && has_digital_update_method<mod>;
         }  // namespace defines
 
         namespace details
@@ -352,6 +411,9 @@ namespace phy_engine
                 virtual model_device_type get_device_type() noexcept = 0;
                 virtual bool has_gpu_table() noexcept = 0;
                 virtual bool gpu_table(gpu_table_rows& rows) noexcept = 0;
+                virtual ::phy_engine::digital::need_operate_analog_node_t
+                    update_digital_clk(::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) noexcept = 0;
+                virtual digital_update_method_t get_digital_update_method() noexcept = 0;
             };
 
             template <typename mod>
@@ -404,6 +466,19 @@ namespace phy_engine
                     if constexpr(defines::can_gpu_table<T>) return gpu_table_define(model_reserve_type<T>, m, rows);
                     else
                         return false;
+                }
+                ::phy_engine::digital::need_operate_analog_node_t
+                    update_digital_clk(::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) noexcept override
+                {
+                    if constexpr(defines::can_update_digital_clk<T>) return update_digital_clk_define(model_reserve_type<T>, m, table, tr_duration, method);
+                    else
+                        return {};
+                }
+                digital_update_method_t get_digital_update_method() noexcept override
+                {
+                    if constexpr(defines::has_digital_update_method<T>) return T::digital_update_method;
+                    else
+                        return digital_update_method_t::update_table;
                 }
             };
         }  // namespace details
@@ -645,6 +720,10 @@ namespace phy_engine
         ::std::size_t branch_counter{};
         ::std::vector<::phy_engine::model::node_t*> size_t_to_node_p{};
         ::std::vector<::phy_engine::model::branch*> size_t_to_branch_p{};
+        ::phy_engine::digital::digital_node_update_table digital_update_tables{};
+        ::std::vector<::phy_engine::digital::need_operate_analog_node_t> digital_out{};
+        ::std::vector<::phy_engine::model::model_base*> before_all_clk_digital_model{};
+        ::std::vector<::phy_engine::model::model_base*> after_all_clk_digital_model{};
         double tr_duration{};
         double last_step{};
         ::std::string last_error{};
@@ -679,11 +758,51 @@ namespace phy_engine
             }
         }
 
+        // circuit.h:298-354: one digital tick.  Runs on the host by design (integer / enum event logic);
+        // models that drive analog nodes are collected in digital_out and become ideal sources of the next analyze().
+        void digital_clk() noexcept
+        {
+            using namespace ::phy_engine::model;
+            digital_out.clear();
+            for(auto* i: before_all_clk_digital_model)
+            {
+                auto const rt = i->ptr->update_digital_clk(digital_update_tables, tr_duration, digital_update_method_t::before_all_clk);
+                if(rt.need_to_operate_analog_node) digital_out.push_back(rt);
+            }
+            if(!digital_update_tables.always_tables.empty())
+                digital_update_tables.tables.insert(digital_update_tables.always_tables.begin(), digital_update_tables.always_tables.end());
+            ::std::size_t budget{10'000'000};
+            while(!digital_update_tables.tables.empty())
+            {
+                if(budget-- == 0) break;
+                auto it = digital_update_tables.tables.begin();
+                auto* node = *it;
+                digital_update_tables.tables.erase(it);
+                for(auto* p: node->pins)
+                {
+                    auto* m = p->model;
+                    if(m && m->ptr && m->ptr->get_device_type() == model_device_type::digital)
+                    {
+                        auto const rt = m->ptr->update_digital_clk(digital_update_tables, tr_duration, digital_update_method_t::update_table);
+                        if(rt.need_to_operate_analog_node) digital_out.push_back(rt);
+                    }
+                }
+            }
+            for(auto* i: after_all_clk_digital_model)
+            {
+                auto const rt = i->ptr->update_digital_clk(digital_update_tables, tr_duration, digital_update_method_t::after_all_clk);
+                if(rt.need_to_operate_analog_node) digital_out.push_back(rt);
+            }
+        }
+
         // circuit.h:446-465
         void reset() noexcept
         {
             tr_duration = 0.0;
             last_step = 0.0;
+            digital_out.clear();
+            digital_update_tables.always_tables.clear();
+            digital_update_tables.tables.clear();
             for(auto* n: size_t_to_node_p) n->node_information.an.voltage = {};
             for(auto* b: size_t_to_branch_p) b->current = {};
             node_counter = branch_counter = 0;
@@ -698,22 +817,38 @@ namespace phy_engine
         bool prepare() noexcept
         {
             using namespace ::phy_engine::model;
+            digital_update_tables.always_tables.clear();
+            digital_update_tables.tables.clear();
             node_counter = 0;
             size_t_to_node_p.clear();
+            // pin -> model back pointers first (the node classification below looks at the models)
+            for(auto& blk: nl.models)
+                for(auto* c = blk.begin; c != blk.curr; ++c)
+                    if(c->type == model_type::normal)
+                    {
+                        auto const pv = c->ptr->generate_pin_view();
+                        for(::std::size_t i = 0; i < pv.size; ++i) pv.pins[i].model = c;
+                    }
             for(auto& blk: nl.nodes)
                 for(auto* c = blk.begin; c != blk.curr; ++c)
                 {
-                    bool analog = c->num_of_analog_node != 0;
-                    if(!analog)  // merge_node quirk: the survivor may hold analog pins without counting them
-                        for(auto* p: c->pins)
-                            if(p->model && p->model->ptr && p->model->ptr->get_device_type() != model_device_type::digital) analog = true;
-                    if(!analog) continue;
+                    ::std::size_t analog_pins = 0;  // counted from the pins: immune to the merge_node quirk
+                    for(auto* p: c->pins)
+                        if(p->model && p->model->ptr && p->model->ptr->get_device_type() != model_device_type::digital) ++analog_pins;
+                    if(analog_pins == 0)
+                    {
+                        if(!c->pins.empty() && !has_prepare) c->node_information.dn.state = digital_node_statement_t::X;  // circuit.h:485-490
+                        continue;
+                    }
+                    if(analog_pins != c->pins.size()) digital_update_tables.always_tables.emplace(c);  // hybrid (circuit.h:494-497)
                     size_t_to_node_p.push_back(c);
                     c->node_index = node_counter++;
                 }
             nl.ground_node.node_index = SIZE_MAX;
-            branch_counter = 0;
+            branch_counter = digital_out.size();  // digital drives own the leading branch rows (circuit.h:509)
             size_t_to_branch_p.clear();
+            before_all_clk_digital_model.clear();
+            after_all_clk_digital_model.clear();
 
             tables_ next{};
             for(auto& blk: nl.models)
@@ -728,6 +863,14 @@ namespace phy_engine
                     {
                         size_t_to_branch_p.push_back(bv.branches + i);
                         bv.branches[i].index = branch_counter++;
+                    }
+                    if(c->ptr->get_device_type() == model_device_type::digital)
+                    {
+                        auto const method = static_cast<unsigned>(c->ptr->get_digital_update_method());
+                        if(method & static_cast<unsigned>(digital_update_method_t::before_all_clk)) before_all_clk_digital_model.push_back(c);
+                        else if(method & static_cast<unsigned>(digital_update_method_t::after_all_clk))
+                            after_all_clk_digital_model.push_back(c);
+                        continue;  // event logic stays on the host
                     }
                     gpu_table_rows rows{};
                     if(!c->ptr->has_gpu_table() || !c->ptr->gpu_table(rows))
@@ -756,6 +899,12 @@ namespace phy_engine
                 }
             next.n_nodes = static_cast<int>(node_counter);
             next.n_branches = static_cast<int>(branch_counter);
+            for(auto const& d: digital_out)  // ideal sources of circuit.h:1015-1022
+            {
+                auto* n = d.need_to_operate_analog_node;
+                next.drv_node.push_back(n == &nl.ground_node ? 0 : static_cast<int>(n->node_index) + 1);
+                next.drv_volt.push_back(d.voltage);
+            }
 
             if(!gpu_)
             {
@@ -776,6 +925,8 @@ namespace phy_engine
 
             if(!loaded_ || !next.same_topology(resident_))
             {
+                if(pe_hip_set_digital_drives(gpu_, static_cast<int>(next.drv_node.size()), next.drv_node.data(), next.drv_volt.data()) != PE_HIP_OK)
+                    return gpu_fail();
                 ::std::vector<pe_hip_device_table> tabs;
                 for(int k = 1; k <= PE_HIP_DIODE; ++k)
                 {
@@ -794,6 +945,9 @@ namespace phy_engine
             }
             else
             {
+                if(!next.drv_node.empty() && next.drv_volt != resident_.drv_volt &&
+                   pe_hip_set_digital_drives(gpu_, static_cast<int>(next.drv_node.size()), next.drv_node.data(), next.drv_volt.data()) != PE_HIP_OK)
+                    return gpu_fail();
                 // same topology: push changed parameters only
                 for(int k = 1; k <= PE_HIP_DIODE; ++k)
                 {
@@ -831,9 +985,11 @@ namespace phy_engine
         {
             int n_nodes{}, n_branches{};
             table_ kind[PE_HIP_DIODE + 1]{};
+            ::std::vector<int> drv_node;
+            ::std::vector<double> drv_volt;
             bool same_topology(tables_ const& o) const
             {
-                if(n_nodes != o.n_nodes || n_branches != o.n_branches) return false;
+                if(n_nodes != o.n_nodes || n_branches != o.n_branches || drv_node != o.drv_node) return false;
                 for(int k = 1; k <= PE_HIP_DIODE; ++k)
                     if(kind[k].nodes != o.kind[k].nodes || kind[k].branch != o.kind[k].branch || kind[k].params.size() != o.kind[k].params.size()) return false;
                 return true;

@@ -15,7 +15,7 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke"]
+TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")
@@ -29,6 +29,33 @@ def built():
 def test_reference_style_program(built, name):
     out = subprocess.run([os.path.join(built, name)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, f"{name} exited {out.returncode}: {out.stderr}"
+
+
+@pytest.mark.gpu
+def test_adc_mixed_signal_matches_reference(built):
+    """Config C4: flash ADC (analog ladder on the GPU, comparators + NOT/AND one-hot encoder on the host event queue).
+    Digital outputs and comparator states bit-exact against the real reference (tests/golden/adc_c4.json, made by
+    oracle/ref_adc.cpp); ladder node voltages within 1e-12.  The sample vin = 8/16 Vref sits EXACTLY on a threshold:
+    the comparator there compares two doubles that differ in the last bits between any two LU implementations, so for
+    that one sample the decision is checked against this engine's own ladder voltage instead of the reference's bit."""
+    import json
+    out = subprocess.run([os.path.join(built, "adc_flash")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout)["samples"]
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "adc_c4.json")))["samples"]
+    assert len(got) == len(ref) == 7
+    for g, r in zip(got, ref):
+        assert g["ok"] == r["ok"] == 1
+        assert abs(g["v_vin"] - r["v_vin"]) <= 1e-12
+        assert max(abs(a - b) for a, b in zip(g["ladder"], r["ladder"])) <= 1e-12
+        on_threshold = any(abs(r["vin"] - t) < 1e-9 for t in r["ladder"][:15])
+        if on_threshold:
+            exp_cmp = [1 if g["v_vin"] >= t else 0 for t in g["ladder"][:15]]
+            assert g["cmp"] == exp_cmp
+            assert sum(g["out"]) == 1 and g["out"].index(1) == sum(exp_cmp)
+        else:
+            assert g["cmp"] == r["cmp"], (g["vin"], g["cmp"], r["cmp"])
+            assert g["out"] == r["out"], (g["vin"], g["out"], r["out"])
 
 
 def test_cpp_api_compiles_and_loader_symbols_exported(built, pe):
