@@ -85,6 +85,7 @@ namespace pe
         // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts
         int const *wave_ptr, *wave_list, *coop_list;
         int n_coop, n_waves;
+        int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)
         int wave_m, wave_p, max_m, max_p;
         int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)
         int lds_sslot;          // doubles of one wavefront's solve scratch

@@ -159,6 +159,7 @@ namespace
         HIPCHK(h, pool.upload(V.coop_list, S.coop_list));
         V.n_coop = static_cast<int>(S.coop_list.size());
         V.n_waves = so.n_waves;
+        V.high_occupancy = batch >= 384 ? 1 : 0;
         V.wave_m = so.wave_m;
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
@@ -200,7 +201,8 @@ namespace
         else
         {
             so.n_waves = 8;
-            so.wave_m = 48;
+            so.wave_m = 56;
+            so.wave_p = 20;
             so.max_pivots = 48;
         }
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
@@ -214,9 +216,10 @@ namespace
         so.wave_p = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_P", so.wave_p));
         so.absorb_m = std::max(1, env_int("PHY_ENGINE_HIP_ABSORB_M", so.absorb_m));
         so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
+        so.cut_factor = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_CUT_X10", static_cast<int>(so.cut_factor * 10.0)));
         so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
         so.wave_p = std::min(so.wave_p, so.max_pivots);
-        long long const lds_doubles = h->lds_limit / 8 - 16;
+        long long const lds_doubles = h->lds_limit / 8 - 160;  // leave room for the static LDS of __syncthreads_or long long const lds_doubles = h->lds_limit / 8 - 16; co.
         // a wave front needs p * (m + u) <= wave_p * 2 * wave_m doubles of LDS; keep all wavefronts' slots within the limit
         while(static_cast<long long>(so.n_waves) * so.wave_p * 2 * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
         so.absorb_m = std::min(so.absorb_m, so.wave_m);

@@ -147,7 +147,11 @@ namespace pe
     // dynamic LDS: V.lds_doubles doubles, carved per phase by pe_front.hpp
     extern __shared__ __attribute__((aligned(16))) double pe_lds[];
 
-    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_tr_steps(DevView V, double dt, int nsteps, int reuse_factor)
+    // Two register budgets of the same code: MINW = 2 -> up to 256 VGPRs (one 512-thread workgroup per CU: few
+    // instances, lowest latency, no spills); MINW = 4 -> 128 VGPRs (2-4 workgroups per CU: a sweep that oversubscribes
+    // the chip hides each workgroup's dependent-latency chains behind the others).
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_tr_steps(DevView V, double dt, int nsteps, int reuse_factor)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
@@ -155,7 +159,8 @@ namespace pe
         tr_steps(tm, V, b, dt, nsteps, reuse_factor != 0, pe_lds);
     }
 
-    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_dc_point(DevView V, int mode)
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_dc_point(DevView V, int mode)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
@@ -164,7 +169,7 @@ namespace pe
     }
 
     // A x = b with A values / rhs already resident (solve_csr_real seam): factor + solve, instance 0..batch-1
-    __global__ void __launch_bounds__(PE_THREADS, PE_MIN_WAVES_PER_SIMD) k_factor_solve(DevView V, int do_factor)
+    __global__ void __launch_bounds__(PE_THREADS, 2) k_factor_solve(DevView V, int do_factor)
     {
         int const b = static_cast<int>(blockIdx.x);
         if(b >= V.batch) return;
@@ -191,18 +196,20 @@ namespace pe
     hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
-        hipError_t e = set_lds(reinterpret_cast<void const*>(&k_tr_steps), lds);
+        auto const fn = V.high_occupancy ? &k_tr_steps<4> : &k_tr_steps<2>;
+        hipError_t e = set_lds(reinterpret_cast<void const*>(fn), lds);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_tr_steps, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, dt, nsteps, reuse ? 1 : 0);
+        hipLaunchKernelGGL(fn, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, dt, nsteps, reuse ? 1 : 0);
         return hipGetLastError();
     }
 
     hipError_t launch_dc_point(hipStream_t st, DevView const& V, int mode)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
-        hipError_t e = set_lds(reinterpret_cast<void const*>(&k_dc_point), lds);
+        auto const fn = V.high_occupancy ? &k_dc_point<4> : &k_dc_point<2>;
+        hipError_t e = set_lds(reinterpret_cast<void const*>(fn), lds);
         if(e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_dc_point, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, mode);
+        hipLaunchKernelGGL(fn, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, mode);
         return hipGetLastError();
     }
 

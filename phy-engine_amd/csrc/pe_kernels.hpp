@@ -10,10 +10,6 @@
     #define PE_THREADS 512  // upper bound (launch bounds); a launch uses V.n_waves * 64 threads
 #endif
 
-#ifndef PE_MIN_WAVES_PER_SIMD
-    #define PE_MIN_WAVES_PER_SIMD 4  // <= 128 VGPRs: two 512-thread (or four 256-thread) workgroups per CU
-#endif
-
 namespace pe
 {
     hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse_factor);

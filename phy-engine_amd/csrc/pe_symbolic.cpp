@@ -748,13 +748,52 @@ namespace pe
         }
 
         // ---------------- schedule: wave subtrees (phase 1) + cooperative fronts (phase 2)
-        // a front is a WAVE front when it and its whole subtree fit one wavefront's LDS slot
-        S.f_kind.assign(nf, 0);
-        for(int s = 0; s < nf; ++s)
+        // WAVE fronts: whole subtrees that fit one wavefront's LDS slot AND are small enough that the wavefronts of the
+        // workgroup stay balanced (proportional subtree-to-wavefront mapping: cut the tree from the root downwards until
+        // every remaining subtree costs at most 1/(3 W) of the total).  Everything above the cut is COOPERATIVE, whatever
+        // its size: near the root there is no tree parallelism left and one wavefront alone would crawl.
+        S.f_kind.assign(nf, 1);
         {
-            bool wave = (S.f_p[s] + S.f_u[s]) <= opt.wave_m && S.f_p[s] <= opt.wave_p;
-            for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1] && wave; ++a) wave = S.f_kind[S.f_child[a]] == 0;
-            S.f_kind[s] = wave ? 0 : 1;
+            std::vector<double> cost(nf, 0.0), sub(nf, 0.0);
+            std::vector<char> fits(nf, 1);
+            double total = 0.0;
+            for(int s = 0; s < nf; ++s)
+            {
+                double const m = S.f_p[s] + S.f_u[s];
+                cost[s] = 400.0 + m * m * (2.0 + S.f_p[s]);
+                total += cost[s];
+                fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
+                sub[s] += cost[s];
+                int const P = S.f_parent[s];
+                if(P >= 0)
+                {
+                    sub[P] += sub[s];
+                    if(!fits[s]) fits[P] = 0;
+                }
+            }
+            double const limit = total / (opt.cut_factor * std::max(1, opt.n_waves));
+            ivec stack;
+            for(int s = 0; s < nf; ++s)
+                if(S.f_parent[s] < 0) stack.push_back(s);
+            while(!stack.empty())
+            {
+                int const s = stack.back();
+                stack.pop_back();
+                if(fits[s] && sub[s] <= limit)
+                {
+                    // the whole subtree of s becomes wave work: subtree = contiguous range of fronts ending at s
+                    ivec st2{s};
+                    while(!st2.empty())
+                    {
+                        int const t = st2.back();
+                        st2.pop_back();
+                        S.f_kind[t] = 0;
+                        for(int a = S.f_child_ptr[t]; a < S.f_child_ptr[t + 1]; ++a) st2.push_back(S.f_child[a]);
+                    }
+                }
+                else
+                    for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a) stack.push_back(S.f_child[a]);
+            }
         }
         int const W = std::max(1, opt.n_waves);
         {

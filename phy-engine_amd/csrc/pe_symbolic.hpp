@@ -27,6 +27,7 @@ namespace pe
         int wave_p{24};
         int absorb_m{48};         // a parent absorbs any child while the merged front order stays <= absorb_m (clamped to wave_m)
         int n_waves{8};           // wavefronts per workgroup (static assignment of wave subtrees)
+        double cut_factor{1.0};   // a wave subtree may cost at most total / (cut_factor * n_waves)
         long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
 
