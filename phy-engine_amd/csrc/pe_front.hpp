@@ -412,11 +412,12 @@ namespace pe
                                 double ucol[NB];
 #pragma unroll
                                 for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? Lp[(k0 + r) + (k0 + kk) * m] : 0.0;
+                                double const rdiag = 1.0 / ucol[kk];  // independent of the chain below: overlaps with it
                                 double acc = x[kk];
 #pragma unroll
                                 for(int r = 0; r < NB; ++r)
                                     if(r < kk) acc -= x[r] * ucol[r];
-                                x[kk] = acc / ucol[kk];
+                                x[kk] = acc * rdiag;
                             }
                         }
 #pragma unroll

@@ -41,7 +41,7 @@ namespace pe
                 double const lrk = __shfl(v, r + 8 * kk);
                 double const ukc = __shfl(v, kk + 8 * c);
                 if(kk < kb && (piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))) bad = 1;
-                double const l = lrk / piv;
+                double const l = lrk * (1.0 / piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
                 if(r > kk && c > kk) v -= l * ukc;
                 if(r > kk && c == kk) v = l;
             }

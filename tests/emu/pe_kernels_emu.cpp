@@ -33,7 +33,7 @@ namespace pe
                 if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
                 for(int r = kk + 1; r < kb; ++r)
                 {
-                    double const l = blk[r + kk * ld] / piv;
+                    double const l = blk[r + kk * ld] * (1.0 / piv);
                     for(int c = kk + 1; c < kb; ++c) blk[r + c * ld] -= l * blk[kk + c * ld];
                     blk[r + kk * ld] = l;
                 }
