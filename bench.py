@@ -108,12 +108,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     tdev = None
-    if world > 1:
+    # rehearsal knobs (not used by the driver): several ranks on ONE GPU over gloo, to exercise the N>1 code path on a 1-GPU box
+    backend = os.environ.get("PE_BENCH_BACKEND", "nccl")
+    device_index = int(os.environ.get("PE_BENCH_DEVICE", local_rank))
+    if world > 1 or os.environ.get("PE_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        tdev = torch.device("cuda", local_rank)
-        dist.init_process_group("nccl", device_id=tdev)
+        if backend == "nccl":
+            torch.cuda.set_device(device_index)
+            tdev = torch.device("cuda", device_index)
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            tdev = torch.device("cpu")
+            dist.init_process_group(backend)
 
     pe = pe_load.load()
     W = args.mesh
@@ -122,7 +129,7 @@ def main():
     B = args.batch
     seeds = [rank * B + k + 1 for k in range(B)]
     deck, r, c = pe.deck.rc_mesh_params(W, W, seeds, nonlinear)
-    eng = pe.ffi.Engine(device=local_rank)
+    eng = pe.ffi.Engine(device=device_index)
     eng.set_options(g_min=0.0)
     eng.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
     eng.reset()
@@ -130,9 +137,11 @@ def main():
     def barrier():
         if dist is not None:
             import torch
-            torch.cuda.synchronize()
+            if tdev.type == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if tdev.type == "cuda":
+                torch.cuda.synchronize()
 
     st_w = eng.analyze_tr(dt, args.warmup) if args.warmup > 0 else None
     info = eng.info()
