@@ -91,6 +91,25 @@ def cpu_baseline(deck, dt, nonlinear, budget_steps):
             "sample": f"{n} TR steps of instance seed=1, oracle/pe_oracle.py (scipy SuperLU, refactor every solve), 1 thread"}
 
 
+def single_circuit_numbers(pe, W, dt, device):
+    """One M10k instance (no batch): NL and linear, full refactorisation per solve like the reference; and the linear
+    circuit with the factors reused while dt is unchanged (legitimate for a linear circuit, SURVEY.md 8d -- flagged)."""
+    out = {}
+    for key, nonlinear, refac, steps in (("nl_steps_per_s", True, 1, 30), ("linear_steps_per_s", False, 1, 60), ("linear_reuse_factor_steps_per_s", False, 0, 200)):
+        eng = pe.ffi.Engine(device=device)
+        eng.set_options(g_min=0.0, refactor_every_solve=refac)
+        eng.load_deck(pe.deck.rc_mesh(W, W, 1, nonlinear))
+        eng.reset()
+        eng.analyze_tr(dt, 3)
+        st = eng.analyze_tr(dt, steps)
+        out[key] = st["steps"] / (st["gpu_ms"] * 1e-3)
+        if nonlinear:
+            out["nl_newton_iters_per_s"] = st["newton_iters"] / (st["gpu_ms"] * 1e-3)
+        eng.close()
+    out["note"] = "one workgroup (one CU) per circuit: latency-bound; linear_reuse_factor skips B_factor (stamp + triangular solves only)"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +119,7 @@ def main():
     ap.add_argument("--mesh", type=int, default=100)
     ap.add_argument("--linear", action="store_true", help="VDC-driven linear variant (no diodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the extra single-circuit measurement")
     ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
@@ -209,6 +229,12 @@ def main():
                     line["roofline"]["traffic_note"] = tj.get("note", "")
             except Exception:
                 pass
+        if world == 1 and not args.no_single:
+            # extra (outside the timed region): ONE M10k circuit on the GPU -- the latency-bound case of config C3
+            try:
+                line["single_circuit"] = single_circuit_numbers(pe, W, dt, device_index)
+            except Exception as e:
+                line["single_circuit"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)
