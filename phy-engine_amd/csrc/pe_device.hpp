@@ -83,8 +83,12 @@ namespace pe
         long long const *f_lptr, *f_uptr, *f_sptr;
         int const *row_src, *col_src;
         // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts
-        int const *wave_ptr, *wave_list, *coop_list;
-        int n_coop, n_waves;
+        // part q, wavefront w: wave_list[wave_ptr[q*(n_waves+1)+w] ..); cooperative fronts of part q: coop_list[coop_ptr[q] ..);
+        // top fronts of level l: top_list[top_ptr[l] ..)  (multi-workgroup mode only)
+        int const *wave_ptr, *wave_list, *coop_ptr, *coop_list, *top_ptr, *top_list;
+        int n_parts, n_top_levels, n_waves;
+        int* active;            // [.] multi-workgroup mode: instances still iterating
+        int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)
         int wave_m, wave_p, max_m, max_p;
         int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)

@@ -156,8 +156,12 @@ namespace
         HIPCHK(h, pool.upload(V.col_src, S.col_src));
         HIPCHK(h, pool.upload(V.wave_ptr, S.wave_ptr));
         HIPCHK(h, pool.upload(V.wave_list, S.wave_list));
+        HIPCHK(h, pool.upload(V.coop_ptr, S.coop_ptr));
         HIPCHK(h, pool.upload(V.coop_list, S.coop_list));
-        V.n_coop = static_cast<int>(S.coop_list.size());
+        HIPCHK(h, pool.upload(V.top_ptr, S.top_ptr));
+        HIPCHK(h, pool.upload(V.top_list, S.top_list));
+        V.n_parts = S.n_parts;
+        V.n_top_levels = static_cast<int>(S.top_ptr.size()) - 1;
         V.n_waves = so.n_waves;
         V.high_occupancy = batch >= 384 ? 1 : 0;
         V.wave_m = so.wave_m;

@@ -546,17 +546,19 @@ namespace pe
         return true;
     }
 
+    // one PART of the tree (single-workgroup mode: part 0 = everything): wave fronts, then the part's cooperative fronts
     template <class Team>
-    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds)
+    PE_DEV bool factor_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
         int fail = 0;
         long long const c0 = tm.clock();
+        int const* wp = V.wave_ptr + part * (V.n_waves + 1);
         tm.for_each_wave(
             [&](int w, int lane, int NL)
             {
                 auto wt = tm.wave_team(lane);
                 double* slot = lds + static_cast<long long>(w) * V.lds_slot;
-                for(int q = V.wave_ptr[w]; q < V.wave_ptr[w + 1]; ++q)
+                for(int q = wp[w]; q < wp[w + 1]; ++q)
                     if(!front_factor(wt, V, b, V.wave_list[q], slot, false))
                     {
                         fail = 1;
@@ -565,14 +567,20 @@ namespace pe
             });
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
-        for(int q = 0; q < V.n_coop; ++q)
+        for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q)
             if(!front_factor(tm, V, b, V.coop_list[q], lds, true)) return false;
-        if(V.prof && tm.tid() == 0)
+        if(V.prof && tm.tid() == 0 && part == 0)
         {
             V.prof[b * 8 + 1] += c1 - c0;
             V.prof[b * 8 + 2] += tm.clock() - c1;
         }
         return true;
+    }
+
+    template <class Team>
+    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds)
+    {
+        return factor_part(tm, V, b, 0, lds);
     }
 
     // ================================================================================================
@@ -720,6 +728,38 @@ namespace pe
     }
 
     template <class Team>
+    PE_DEV void forward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
+    {
+        int const* wp = V.wave_ptr + part * (V.n_waves + 1);
+        tm.for_each_wave(
+            [&](int wv, int lane, int NL)
+            {
+                auto wt = tm.wave_team(lane);
+                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
+                for(int q = wp[wv]; q < wp[wv + 1]; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+            });
+        tm.sync();
+        for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
+    }
+
+    template <class Team>
+    PE_DEV void backward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
+    {
+        int const* wp = V.wave_ptr + part * (V.n_waves + 1);
+        for(int q = V.coop_ptr[part + 1] - 1; q >= V.coop_ptr[part]; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
+        tm.sync();
+        tm.for_each_wave(
+            [&](int wv, int lane, int NL)
+            {
+                auto wt = tm.wave_team(lane);
+                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
+                for(int q = wp[wv + 1] - 1; q >= wp[wv]; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+            });
+        tm.sync();
+    }
+
+    // single-workgroup mode: the whole tree is part 0
+    template <class Team>
     PE_DEV void solve_all(Team const& tm, DevView const& V, int b, double* lds)
     {
         int const T = tm.size(), t0 = tm.tid();
@@ -729,32 +769,13 @@ namespace pe
         for(int k = t0; k < V.rows; k += T) w[k] = rhs[V.row_src[k]];
         tm.sync();
         long long const c0 = tm.clock();
-        tm.for_each_wave(
-            [&](int wv, int lane, int NL)
-            {
-                auto wt = tm.wave_team(lane);
-                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = V.wave_ptr[wv]; q < V.wave_ptr[wv + 1]; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
-            });
-        tm.sync();
+        forward_part(tm, V, b, 0, lds);
         long long const c1 = tm.clock();
-        for(int q = 0; q < V.n_coop; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
-        for(int q = V.n_coop - 1; q >= 0; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
-        tm.sync();
-        long long const c2 = tm.clock();
-        tm.for_each_wave(
-            [&](int wv, int lane, int NL)
-            {
-                auto wt = tm.wave_team(lane);
-                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = V.wave_ptr[wv + 1] - 1; q >= V.wave_ptr[wv]; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
-            });
-        tm.sync();
+        backward_part(tm, V, b, 0, lds);
         if(V.prof && t0 == 0)
         {
             V.prof[b * 8 + 3] += c1 - c0;
-            V.prof[b * 8 + 4] += c2 - c1;
-            V.prof[b * 8 + 5] += tm.clock() - c2;
+            V.prof[b * 8 + 5] += tm.clock() - c1;
         }
         for(int k = t0; k < V.rows; k += T) x[V.col_src[k]] = w[k];
         tm.sync();

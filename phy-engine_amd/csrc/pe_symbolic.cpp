@@ -747,93 +747,163 @@ namespace pe
             }
         }
 
-        // ---------------- schedule: wave subtrees (phase 1) + cooperative fronts (phase 2)
-        // WAVE fronts: whole subtrees that fit one wavefront's LDS slot AND are small enough that the wavefronts of the
-        // workgroup stay balanced (proportional subtree-to-wavefront mapping: cut the tree from the root downwards until
-        // every remaining subtree costs at most 1/(3 W) of the total).  Everything above the cut is COOPERATIVE, whatever
-        // its size: near the root there is no tree parallelism left and one wavefront alone would crawl.
+        // ---------------- schedule
+        // Two nested proportional cuts of the assembly tree (from the roots downwards):
+        //   level 1 (only when n_parts > 1, the multi-workgroup mode for one or few instances): subtrees costing at most
+        //           total / (n_parts * part_cut) become PART subtrees, spread over n_parts workgroups; what stays above is
+        //           the TOP, processed one tree level per kernel launch with one workgroup per front;
+        //   level 2 (inside every part): subtrees that fit one wavefront's LDS slot and cost at most
+        //           part_total / (W * cut_factor) become WAVE subtrees, spread over the W wavefronts of the workgroup;
+        //           the rest of the part is COOPERATIVE (whole workgroup).
+        // Near a root there is no tree parallelism left, so the upper fronts are always handled by the wider executor.
+        int const W = std::max(1, opt.n_waves);
+        int const K = std::max(1, opt.n_parts);
+        S.n_parts = K;
         S.f_kind.assign(nf, 1);
+        ivec part_of(nf, K > 1 ? -1 : 0);
+        std::vector<double> cost(nf, 0.0), sub(nf, 0.0);
+        std::vector<char> fits(nf, 1);
+        double total = 0.0;
+        for(int s = 0; s < nf; ++s)
         {
-            std::vector<double> cost(nf, 0.0), sub(nf, 0.0);
-            std::vector<char> fits(nf, 1);
-            double total = 0.0;
-            for(int s = 0; s < nf; ++s)
+            double const m = S.f_p[s] + S.f_u[s];
+            cost[s] = 400.0 + m * m * (2.0 + S.f_p[s]);
+            total += cost[s];
+            fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
+            sub[s] += cost[s];
+            int const P = S.f_parent[s];
+            if(P >= 0)
             {
-                double const m = S.f_p[s] + S.f_u[s];
-                cost[s] = 400.0 + m * m * (2.0 + S.f_p[s]);
-                total += cost[s];
-                fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
-                sub[s] += cost[s];
-                int const P = S.f_parent[s];
-                if(P >= 0)
-                {
-                    sub[P] += sub[s];
-                    if(!fits[s]) fits[P] = 0;
-                }
+                sub[P] += sub[s];
+                if(!fits[s]) fits[P] = 0;
             }
-            double const limit = total / (opt.cut_factor * std::max(1, opt.n_waves));
-            ivec stack;
+        }
+        auto mark_subtree = [&](int root, auto&& fn)
+        {
+            ivec st2{root};
+            while(!st2.empty())
+            {
+                int const t = st2.back();
+                st2.pop_back();
+                fn(t);
+                for(int a = S.f_child_ptr[t]; a < S.f_child_ptr[t + 1]; ++a) st2.push_back(S.f_child[a]);
+            }
+        };
+        std::vector<double> part_total(K, 0.0);
+        if(K > 1)
+        {
+            double const limit1 = total / (static_cast<double>(K) * opt.part_cut);
+            ivec stack, sroots;
             for(int s = 0; s < nf; ++s)
                 if(S.f_parent[s] < 0) stack.push_back(s);
             while(!stack.empty())
             {
                 int const s = stack.back();
                 stack.pop_back();
-                if(fits[s] && sub[s] <= limit)
-                {
-                    // the whole subtree of s becomes wave work: subtree = contiguous range of fronts ending at s
-                    ivec st2{s};
-                    while(!st2.empty())
-                    {
-                        int const t = st2.back();
-                        st2.pop_back();
-                        S.f_kind[t] = 0;
-                        for(int a = S.f_child_ptr[t]; a < S.f_child_ptr[t + 1]; ++a) st2.push_back(S.f_child[a]);
-                    }
-                }
+                if(sub[s] <= limit1) sroots.push_back(s);
                 else
                     for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a) stack.push_back(S.f_child[a]);
             }
+            std::sort(sroots.begin(), sroots.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+            for(int r: sroots)
+            {
+                int const pidx = static_cast<int>(std::min_element(part_total.begin(), part_total.end()) - part_total.begin());
+                part_total[pidx] += sub[r];
+                mark_subtree(r, [&](int t) { part_of[t] = pidx; });
+            }
         }
-        int const W = std::max(1, opt.n_waves);
+        else
+            part_total[0] = total;
+        // level 2
+        for(int s = nf - 1; s >= 0; --s)
         {
-            // subtree roots = wave fronts whose parent is cooperative (or absent); LPT assignment to W waves
-            ivec root_of(nf, -1);
-            std::vector<double> cost(nf, 0.0);
+            if(part_of[s] < 0)
+            {
+                S.f_kind[s] = 2;
+                continue;
+            }
+            int const P = S.f_parent[s];
+            bool const parent_is_wave = P >= 0 && part_of[P] == part_of[s] && S.f_kind[P] == 0;
+            if(parent_is_wave) S.f_kind[s] = 0;  // inside a wave subtree
+            else
+            {
+                double const limit2 = part_total[part_of[s]] / (opt.cut_factor * W);
+                S.f_kind[s] = (fits[s] && sub[s] <= limit2) ? 0 : 1;
+            }
+        }
+        // executors: wave w of part q -> q * (W + 1) + w ; cooperative phase of part q -> q * (W + 1) + W ; top fronts: none
+        ivec exec_of(nf, -1), wroot_of(nf, -1);
+        {
+            // wave subtree roots per part, LPT over the W wavefronts
+            std::vector<ivec> wroots(K);
             for(int s = nf - 1; s >= 0; --s)
             {
                 if(S.f_kind[s] != 0) continue;
                 int const P = S.f_parent[s];
-                root_of[s] = (P >= 0 && S.f_kind[P] == 0) ? root_of[P] : s;
+                bool const inner = P >= 0 && part_of[P] == part_of[s] && S.f_kind[P] == 0;
+                wroot_of[s] = inner ? wroot_of[P] : s;
+                if(!inner) wroots[part_of[s]].push_back(s);
+            }
+            for(int q = 0; q < K; ++q)
+            {
+                auto& r = wroots[q];
+                std::sort(r.begin(), r.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+                std::vector<double> load(W, 0.0);
+                for(int root: r)
+                {
+                    int const w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+                    load[w] += sub[root];
+                    exec_of[root] = q * (W + 1) + w;
+                }
             }
             for(int s = 0; s < nf; ++s)
             {
-                if(S.f_kind[s] != 0) continue;
-                double const m = S.f_p[s] + S.f_u[s];
-                cost[root_of[s]] += 400.0 + m * m * (2.0 + S.f_p[s]);
+                if(S.f_kind[s] == 0) exec_of[s] = exec_of[wroot_of[s]];
+                else if(S.f_kind[s] == 1)
+                    exec_of[s] = part_of[s] * (W + 1) + W;
             }
-            ivec roots;
+        }
+        // lists (ascending front index = postorder inside every executor)
+        {
+            std::vector<ivec> lists(static_cast<size_t>(K) * (W + 1));
             for(int s = 0; s < nf; ++s)
-                if(S.f_kind[s] == 0 && root_of[s] == s) roots.push_back(s);
-            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
-            std::vector<double> load(W, 0.0);
-            ivec wave_of_root(nf, -1);
-            for(int r: roots)
-            {
-                int const w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
-                load[w] += cost[r];
-                wave_of_root[r] = w;
-            }
-            std::vector<ivec> lists(W);
-            for(int s = 0; s < nf; ++s)
-                if(S.f_kind[s] == 0) lists[wave_of_root[root_of[s]]].push_back(s);  // ascending = postorder
-            S.wave_ptr.assign(W + 1, 0);
-            for(int w = 0; w < W; ++w) S.wave_ptr[w + 1] = S.wave_ptr[w] + static_cast<int>(lists[w].size());
+                if(exec_of[s] >= 0) lists[exec_of[s]].push_back(s);
+            S.wave_ptr.assign(static_cast<size_t>(K) * (W + 1) + 1, 0);  // per part: W wave lists (entry W of a part is empty, keeps the stride)
             S.wave_list.clear();
-            for(int w = 0; w < W; ++w) S.wave_list.insert(S.wave_list.end(), lists[w].begin(), lists[w].end());
+            S.coop_ptr.assign(K + 1, 0);
             S.coop_list.clear();
+            for(int q = 0; q < K; ++q)
+            {
+                for(int w = 0; w <= W; ++w)
+                {
+                    size_t const e = static_cast<size_t>(q) * (W + 1) + w;
+                    if(w < W) S.wave_list.insert(S.wave_list.end(), lists[e].begin(), lists[e].end());
+                    S.wave_ptr[e + 1] = static_cast<int>(S.wave_list.size());
+                }
+                auto const& cl = lists[static_cast<size_t>(q) * (W + 1) + W];
+                S.coop_list.insert(S.coop_list.end(), cl.begin(), cl.end());
+                S.coop_ptr[q + 1] = static_cast<int>(S.coop_list.size());
+            }
+            // top levels: height above the parts
+            ivec h(nf, 0);
+            int maxh = 0;
             for(int s = 0; s < nf; ++s)
-                if(S.f_kind[s] == 1) S.coop_list.push_back(s);
+            {
+                if(S.f_kind[s] != 2) continue;
+                int hh = 1;
+                for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
+                    if(S.f_kind[S.f_child[a]] == 2) hh = std::max(hh, h[S.f_child[a]] + 1);
+                h[s] = hh;
+                maxh = std::max(maxh, hh);
+            }
+            S.top_ptr.assign(maxh + 1, 0);
+            S.top_list.clear();
+            for(int lev = 1; lev <= maxh; ++lev)
+            {
+                for(int s = 0; s < nf; ++s)
+                    if(S.f_kind[s] == 2 && h[s] == lev) S.top_list.push_back(s);
+                S.top_ptr[lev] = static_cast<int>(S.top_list.size());
+            }
 
             // storage offsets: factor panels
             S.f_lptr.resize(nf);
@@ -849,29 +919,35 @@ namespace pe
                 fo += p * u;
             }
             S.factor_doubles = fo;
-            // update-matrix arena: [persistent: roots of wave subtrees][one stack per wave][cooperative stack]
+            // update-matrix arena.  A front whose parent runs on a different executor (or is a top front) keeps its update
+            // matrix in a persistent slot; inside one executor the matrices live on TWO LIFO stacks chosen by the parity of
+            // the tree depth: a front writes its Schur tiles while later tiles still gather from its children's, so a parent
+            // must never overlap its children -- children always sit on the other stack.
             long long base = 0;
-            for(int r: roots)
+            auto persistent = [&](int s)
             {
-                S.f_sptr[r] = base;
-                base += static_cast<long long>(S.f_u[r]) * S.f_u[r];
-            }
-            // A front writes its update matrix tile by tile while later tiles still gather from its children's, so a
-            // parent must never overlap its children: TWO LIFO stacks per executor (each wavefront, and the
-            // cooperative phase), chosen by the parity of the tree depth -- children always sit on the other stack.
-            for(int w = 0; w < W; ++w)
+                int const P = S.f_parent[s];
+                return exec_of[s] < 0 || P < 0 || exec_of[P] != exec_of[s];
+            };
+            for(int s = 0; s < nf; ++s)
+                if(persistent(s))
+                {
+                    S.f_sptr[s] = base;
+                    base += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                }
+            for(auto const& lst: lists)
             {
                 long long sp[2] = {0, 0}, peak[2] = {0, 0};
-                std::vector<long long> rel_off(lists[w].size(), 0);
-                for(size_t qi = 0; qi < lists[w].size(); ++qi)
+                std::vector<long long> rel_off(lst.size(), 0);
+                for(size_t qi = 0; qi < lst.size(); ++qi)
                 {
-                    int const s = lists[w][qi];
+                    int const s = lst[qi];
                     for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
                     {
-                        int const c = S.f_child[a];  // children of a wave front are non-root wave fronts of the same wave
-                        sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
+                        int const c = S.f_child[a];
+                        if(!persistent(c)) sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
                     }
-                    if(root_of[s] == s) continue;  // roots live in the persistent region
+                    if(persistent(s)) continue;
                     int const q = depth[s] & 1;
                     rel_off[qi] = sp[q];
                     sp[q] += static_cast<long long>(S.f_u[s]) * S.f_u[s];
@@ -879,44 +955,17 @@ namespace pe
                 }
                 if(sp[0] != 0 || sp[1] != 0)
                 {
-                    S.error = "internal: wave stacks not empty at the end";
+                    S.error = "internal: executor stacks not empty at the end";
                     return false;
                 }
-                for(size_t qi = 0; qi < lists[w].size(); ++qi)
+                for(size_t qi = 0; qi < lst.size(); ++qi)
                 {
-                    int const s = lists[w][qi];
-                    if(root_of[s] != s) S.f_sptr[s] = base + ((depth[s] & 1) ? peak[0] : 0) + rel_off[qi];
+                    int const s = lst[qi];
+                    if(!persistent(s)) S.f_sptr[s] = base + ((depth[s] & 1) ? peak[0] : 0) + rel_off[qi];
                 }
                 base += peak[0] + peak[1];
             }
-            {
-                // Cooperative fronts write their update matrix while other wavefronts still gather from the children's,
-                // so a parent must never overlap its children: two LIFO stacks, chosen by the parity of the tree depth
-                // (children always live on the other stack; both stay LIFO in postorder).
-                long long sp[2] = {0, 0}, peak[2] = {0, 0};
-                std::vector<long long> rel_off(nf, 0);
-                for(int s: S.coop_list)
-                {
-                    int const q = depth[s] & 1;
-                    for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
-                    {
-                        int const c = S.f_child[a];
-                        if(S.f_kind[c] == 1) sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
-                    }
-                    rel_off[s] = sp[q];
-                    sp[q] += static_cast<long long>(S.f_u[s]) * S.f_u[s];
-                    peak[q] = std::max(peak[q], sp[q]);
-                }
-                if(sp[0] != 0 || sp[1] != 0)
-                {
-                    // roots have u == 0, so both stacks must be empty at the end
-                    S.error = "internal: cooperative stacks not empty at the end";
-                    return false;
-                }
-                for(int s: S.coop_list) S.f_sptr[s] = base + ((depth[s] & 1) ? peak[0] : 0) + rel_off[s];
-                base += peak[0] + peak[1];
-                S.work_doubles = 0;
-            }
+            S.work_doubles = 0;
             S.arena_doubles = base;
         }
         // inverse relative maps of every parent front

@@ -27,7 +27,9 @@ namespace pe
         int wave_p{24};
         int absorb_m{48};         // a parent absorbs any child while the merged front order stays <= absorb_m (clamped to wave_m)
         int n_waves{8};           // wavefronts per workgroup (static assignment of wave subtrees)
-        double cut_factor{1.0};   // a wave subtree may cost at most total / (cut_factor * n_waves)
+        double cut_factor{1.0};   // a wave subtree may cost at most part_total / (cut_factor * n_waves)
+        int n_parts{1};           // > 1: multi-workgroup mode, the tree below the level-1 cut is spread over this many workgroups
+        double part_cut{1.5};     // a part subtree may cost at most total / (n_parts * part_cut)
         long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
 
@@ -59,9 +61,12 @@ namespace pe
         long long arena_doubles{};
         long long work_doubles{};               // (unused)
         long long wave_panel_doubles{};         // largest p*(m+u) of a wave front (LDS doubles of one wavefront's slot)
-        std::vector<int> f_kind;                // 0: wave front, 1: cooperative front
-        std::vector<int> wave_ptr, wave_list;   // phase 1: fronts of wave w = wave_list[wave_ptr[w] .. wave_ptr[w+1]) in postorder
-        std::vector<int> coop_list;             // phase 2: cooperative fronts in postorder
+        std::vector<int> f_kind;                // 0: wave front, 1: cooperative front of a part, 2: top front
+        int n_parts{1};
+        // part q, wavefront w: wave_list[wave_ptr[q*(W+1)+w] .. wave_ptr[q*(W+1)+w+1]) in postorder (entry W of a part is empty)
+        std::vector<int> wave_ptr, wave_list;
+        std::vector<int> coop_ptr, coop_list;   // cooperative fronts of part q: coop_list[coop_ptr[q] .. coop_ptr[q+1])
+        std::vector<int> top_ptr, top_list;     // top fronts of level l (0-based): top_list[top_ptr[l] .. top_ptr[l+1]); children before parents
         // pull-based assembly of the Schur blocks: for child edge e (position in f_child),
         // f_inv[f_inv_off[e] + r] = index of parent-local row r among the child's update rows, or -1
         std::vector<long long> f_inv_off;
