@@ -87,6 +87,7 @@ namespace pe
         // top fronts of level l: top_list[top_ptr[l] ..)  (multi-workgroup mode only)
         int const *wave_ptr, *wave_list, *coop_ptr, *coop_list, *top_ptr, *top_list;
         int n_parts, n_top_levels, n_waves;
+        int top_cnt[16];        // fronts per top level (host-side copy for the launch geometry)
         int* active;            // [.] multi-workgroup mode: instances still iterating
         int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -162,6 +163,8 @@ namespace
         HIPCHK(h, pool.upload(V.top_list, S.top_list));
         V.n_parts = S.n_parts;
         V.n_top_levels = static_cast<int>(S.top_ptr.size()) - 1;
+        if(V.n_top_levels > 16) return fail(h, PE_HIP_ERR_INTERNAL, "assembly tree has more than 16 top levels");
+        for(int l = 0; l < V.n_top_levels; ++l) V.top_cnt[l] = S.top_ptr[l + 1] - S.top_ptr[l];
         V.n_waves = so.n_waves;
         V.high_occupancy = batch >= 384 ? 1 : 0;
         V.wave_m = so.wave_m;
@@ -185,7 +188,7 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
-    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch)
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch, int rows)
     {
         pe::SymbolicOptions so{};
         // workgroup geometry by batch size (measured on MI355X, profiles/): few instances -> one big workgroup per CU;
@@ -209,6 +212,9 @@ namespace
             so.wave_p = 20;
             so.max_pivots = 48;
         }
+        // one or few instances of a large circuit: spread each instance over several workgroups (multi-workgroup mode)
+        // (measured, profiles/: pays while instances x parts <= ~256 workgroups; 32-48 parts for a single M10k circuit)
+        if(rows >= 3000 && batch <= 128) so.n_parts = std::clamp(256 / std::max(1, batch), 1, 48);
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
         auto env_int = [](char const* name, int def)
         {
@@ -222,8 +228,10 @@ namespace
         so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
         so.cut_factor = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_CUT_X10", static_cast<int>(so.cut_factor * 10.0)));
         so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
+        so.n_parts = std::clamp(env_int("PHY_ENGINE_HIP_PARTS", so.n_parts), 1, 64);
+        so.part_cut = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_PART_CUT_X10", static_cast<int>(so.part_cut * 10.0)));
         so.wave_p = std::min(so.wave_p, so.max_pivots);
-        long long const lds_doubles = h->lds_limit / 8 - 160;  // leave room for the static LDS of __syncthreads_or long long const lds_doubles = h->lds_limit / 8 - 16; co.
+        long long const lds_doubles = h->lds_limit / 8 - 160;  // leave room for the static LDS of __syncthreads_or & co.
         // a wave front needs p * (m + u) <= wave_p * 2 * wave_m doubles of LDS; keep all wavefronts' slots within the limit
         while(static_cast<long long>(so.n_waves) * so.wave_p * 2 * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
@@ -238,11 +246,25 @@ namespace
         auto const t0 = clk::now();
         std::vector<double> av;
         pe::estimate_values(h->hc, tr, dt, h->opt.g_min, av);
-        pe::SymbolicOptions const so = symbolic_options(h, h->hc.batch);
+        pe::SymbolicOptions const so = symbolic_options(h, h->hc.batch, h->hc.rows);
         if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
         {
             h->sym_class = -1;
             return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
+        }
+        if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
+        {
+            auto const& S = h->sym;
+            int nk[3]{};
+            for(int s = 0; s < S.nfronts; ++s) ++nk[S.f_kind[s]];
+            std::fprintf(stderr, "[pe_hip] schedule: %d fronts (%d wave, %d cooperative, %d top), %d parts, %d top levels\n", S.nfronts, nk[0], nk[1],
+                         nk[2], S.n_parts, static_cast<int>(S.top_ptr.size()) - 1);
+            for(std::size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
+            {
+                std::fprintf(stderr, "[pe_hip]   top level %zu:", l);
+                for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) std::fprintf(stderr, " %dx%d", S.f_p[S.top_list[k]] + S.f_u[S.top_list[k]], S.f_p[S.top_list[k]]);
+                std::fprintf(stderr, "\n");
+            }
         }
         h->sym_pool.release();
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
@@ -295,6 +317,168 @@ namespace
         HIPCHK(h, hipMemcpy(s0.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy(i0.data(), h->V.n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
         return PE_HIP_OK;
+    }
+}  // namespace
+
+namespace
+{
+    // ---------------- multi-workgroup mode: the Newton / TR loops of circult::solve / analyze (circuit.h:892-985, 233-256)
+    // driven from the host, one kernel sequence per Newton iteration (pe_kernels.hip: launch_m2_iteration)
+    struct M2State
+    {
+        std::vector<int> status, active, flags;
+        std::vector<long long> steps, iters;
+        std::vector<double> t;
+        std::vector<int> trace;
+    };
+
+    int m2_pull(pe_hip_engine* h, M2State& S)
+    {
+        int const B = h->hc.batch;
+        S.status.resize(B);
+        S.active.assign(B, 0);
+        S.flags.assign(B, 0);
+        S.steps.resize(B);
+        S.iters.resize(B);
+        S.t.resize(B);
+        HIPCHK(h, hipMemcpy(S.status.data(), h->V.status, B * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(S.steps.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(S.iters.data(), h->V.n_iters, B * sizeof(long long), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(S.t.data(), h->V.t_now, B * sizeof(double), hipMemcpyDeviceToHost));
+        return PE_HIP_OK;
+    }
+
+    int m2_push(pe_hip_engine* h, M2State const& S, double last_step, bool write_last_step)
+    {
+        int const B = h->hc.batch;
+        HIPCHK(h, hipMemcpy(h->V.status, S.status.data(), B * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->V.n_steps, S.steps.data(), B * sizeof(long long), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->V.n_iters, S.iters.data(), B * sizeof(long long), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->V.t_now, S.t.data(), B * sizeof(double), hipMemcpyHostToDevice));
+        if(write_last_step)
+        {
+            std::vector<double> ls(B, last_step);
+            HIPCHK(h, hipMemcpy(h->V.last_step, ls.data(), B * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if(!S.trace.empty())
+        {
+            int len = 0;
+            HIPCHK(h, hipMemcpy(&len, h->V.trace_len, sizeof(int), hipMemcpyDeviceToHost));
+            int const room = std::max(0, h->V.trace_cap - len);
+            int const n = std::min<int>(room, static_cast<int>(S.trace.size()));
+            if(n > 0) HIPCHK(h, hipMemcpy(h->V.trace + len, S.trace.data(), n * sizeof(int), hipMemcpyHostToDevice));
+            len += static_cast<int>(S.trace.size());
+            HIPCHK(h, hipMemcpy(h->V.trace_len, &len, sizeof(int), hipMemcpyHostToDevice));
+        }
+        return PE_HIP_OK;
+    }
+
+    // one solve point of every instance whose status is OK; result[b] = iterations (> 0) or a negative status
+    int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, std::vector<int>& result, int& launches)
+    {
+        int const B = h->hc.batch;
+        result.assign(B, 0);
+        int n_active = 0;
+        for(int b = 0; b < B; ++b)
+        {
+            S.active[b] = S.status[b] == PE_HIP_OK ? 1 : 0;
+            n_active += S.active[b];
+        }
+        int const max_it = h->hc.nonlinear ? h->V.max_newton : 1;
+        for(int it = 0; it < max_it && n_active > 0; ++it)
+        {
+            HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, true));
+            ++launches;
+            HIPCHK(h, hipMemcpyAsync(S.flags.data(), h->V.flags, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            for(int b = 0; b < B; ++b)
+            {
+                if(!S.active[b]) continue;
+                int const f = S.flags[b];
+                if(f & 5) result[b] = PE_HIP_ERR_SINGULAR;
+                else if(!h->hc.nonlinear || !(f & 2))
+                    result[b] = it + 1;
+                else
+                    continue;
+                S.active[b] = 0;
+                --n_active;
+            }
+        }
+        for(int b = 0; b < B; ++b)
+            if(S.active[b])
+            {
+                result[b] = PE_HIP_ERR_NO_CONVERGENCE;
+                S.active[b] = 0;
+            }
+        return PE_HIP_OK;
+    }
+
+    int run_m2_tr(pe_hip_engine* h, double dt, int nsteps, int& launches)
+    {
+        M2State S;
+        int rc = m2_pull(h, S);
+        if(rc != PE_HIP_OK) return rc;
+        int const B = h->hc.batch;
+        std::vector<int> res;
+        for(int s = 0; s < nsteps; ++s)
+        {
+            int alive = 0;
+            for(int b = 0; b < B; ++b)
+            {
+                S.active[b] = S.status[b] == PE_HIP_OK ? 1 : 0;
+                alive += S.active[b];
+            }
+            if(!alive) break;
+            HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
+            // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
+            double t_prev = 0.0;
+            for(int b = 0; b < B; ++b)
+                if(S.active[b])
+                {
+                    t_prev = S.t[b];
+                    break;
+                }
+            double const t = t_prev + dt;
+            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, res, launches);
+            if(rc != PE_HIP_OK) return rc;
+            for(int b = 0; b < B; ++b)
+            {
+                if(S.status[b] != PE_HIP_OK || res[b] == 0) continue;
+                if(b == 0) S.trace.push_back(res[b]);
+                if(res[b] < 0) S.status[b] = res[b];  // the failing step is rolled back: t stays at t_prev (circuit.h:249-253)
+                else
+                {
+                    S.t[b] = t;
+                    ++S.steps[b];
+                    S.iters[b] += res[b];
+                }
+            }
+        }
+        return m2_push(h, S, dt, true);
+    }
+
+    int run_m2_dc(pe_hip_engine* h, int mode, int& launches)
+    {
+        M2State S;
+        int rc = m2_pull(h, S);
+        if(rc != PE_HIP_OK) return rc;
+        int const B = h->hc.batch;
+        std::vector<double> ls(B);
+        HIPCHK(h, hipMemcpy(ls.data(), h->V.last_step, B * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<int> res;
+        rc = m2_point(h, S, mode, S.t[0], ls[0], res, launches);
+        if(rc != PE_HIP_OK) return rc;
+        for(int b = 0; b < B; ++b)
+        {
+            if(S.status[b] != PE_HIP_OK || res[b] == 0) continue;
+            if(b == 0) S.trace.push_back(res[b]);
+            if(res[b] < 0) S.status[b] = res[b];
+            else
+                S.iters[b] += res[b];
+        }
+        return m2_push(h, S, 0.0, false);
     }
 }  // namespace
 
@@ -459,6 +643,8 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     HIPCHK(h, P.alloc(V.trace, static_cast<size_t>(V.trace_cap)));
     HIPCHK(h, P.alloc(V.trace_len, 1));
     HIPCHK(h, P.alloc(V.prof, B * 8));
+    HIPCHK(h, P.alloc(V.active, B));
+    HIPCHK(h, P.alloc(V.flags, B));
     // static part of dv
     {
         std::vector<double> dv(B * hc.dv_len, 0.0);
@@ -560,6 +746,12 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     int launches = 0;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     int done = 0;
+    if(h->V.n_parts > 1)
+    {
+        rc = run_m2_tr(h, dt, nsteps, launches);
+        if(rc != PE_HIP_OK) return rc;
+        done = nsteps;
+    }
     while(done < nsteps)
     {
         bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
@@ -601,7 +793,14 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     if(rc != PE_HIP_OK) return rc;
     h->fact_valid = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode));
+    if(h->V.n_parts > 1)
+    {
+        int launches = 0;
+        rc = run_m2_dc(h, mode, launches);
+        if(rc != PE_HIP_OK) return rc;
+    }
+    else
+        HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode));
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -760,7 +959,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
         auto const t0 = clk::now();
         C.have = false;
         C.pool.release();
-        pe::SymbolicOptions const so = symbolic_options(h, 1);
+        pe::SymbolicOptions const so = symbolic_options(h, 1, 0);
         if(!pe::analyze(n, row_ptr, col_ind, values, so, C.sym))
             return fail(h, C.sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "solve_csr_real: " + C.sym.error);
         pe::DevView V{};

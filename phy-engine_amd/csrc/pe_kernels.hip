@@ -188,6 +188,114 @@ namespace pe
         if(tm.tid() == 0) V.status[b] = st;
     }
 
+    // =====================================================================================================
+    // Multi-workgroup mode (one or few instances of a large circuit): the same front code, split at the level-1 cut of
+    // the tree into kernels whose boundaries are the only inter-workgroup synchronisation -- no spin-waits, no
+    // cross-CU visibility protocol.  grid = (work items, instances).
+    // =====================================================================================================
+    struct GridTeam  // elementwise phases: G workgroups share one instance's device / slot / row loops
+    {
+        __device__ __forceinline__ int tid() const { return static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x); }
+        __device__ __forceinline__ int size() const { return static_cast<int>(gridDim.x * blockDim.x); }
+    };
+
+    __global__ void __launch_bounds__(256) k_m2_companion(DevView V, double dt)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        companion_update(GridTeam{}, V, b, dt);
+    }
+
+    __global__ void __launch_bounds__(256) k_m2_eval(DevView V, int mode, double t, double last_step)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double const* x = V.x + static_cast<long long>(b) * V.rows;
+        double* xp = V.xprev + static_cast<long long>(b) * V.rows;
+        for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
+        eval_devices(tm, V, b, mode, t, last_step);
+        if(tm.tid() == 0) V.flags[b] = 0;
+    }
+
+    __global__ void __launch_bounds__(256) k_m2_stamp(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        stamp(GridTeam{}, V, b);
+    }
+
+    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_factor_parts(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        if(!factor_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+    }
+
+    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_factor_top(DevView V, int level)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
+        if(!front_factor(tm, V, b, s, pe_lds, false) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+    }
+
+    __global__ void __launch_bounds__(256) k_m2_winit(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        for(int k = tm.tid(); k < V.rows; k += tm.size()) w[k] = rhs[V.row_src[k]];
+    }
+
+    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_solve_parts(DevView V, int backward)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        if(backward) backward_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds);
+        else
+            forward_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds);
+    }
+
+    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_solve_top(DevView V, int level, int backward)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
+        if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.max_p);
+        else
+            front_forward(tm, V, b, s, pe_lds, V.max_m, V.max_p);
+    }
+
+    __global__ void __launch_bounds__(256) k_m2_finish(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double const* w = V.w + static_cast<long long>(b) * V.rows;
+        double* x = V.x + static_cast<long long>(b) * V.rows;
+        double const* xp = V.xprev + static_cast<long long>(b) * V.rows;
+        int bits = 0;
+        for(int k = tm.tid(); k < V.rows; k += tm.size())
+        {
+            // x[col_src[k]] = w[k]; the Newton test of that row is done right here (xprev was saved by k_m2_eval)
+            int const r = V.col_src[k];
+            double const xn = w[k];
+            x[r] = xn;
+            if(!(fabs(xn) <= 1.7976931348623157e308)) bits |= 1;
+            bool const node = r < V.n_nodes;
+            double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * fmax(fabs(xn), fabs(xp[r]));
+            if(!(fabs(xn - xp[r]) <= tol)) bits |= 2;
+        }
+        if(bits) atomicOr(V.flags + b, bits);
+    }
+
     static hipError_t set_lds(void const* fn, size_t bytes)
     {
         return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
@@ -210,6 +318,43 @@ namespace pe
         hipError_t e = set_lds(reinterpret_cast<void const*>(fn), lds);
         if(e != hipSuccess) return e;
         hipLaunchKernelGGL(fn, dim3(V.batch), dim3(V.n_waves * 64), lds, st, V, mode);
+        return hipGetLastError();
+    }
+
+    // one Newton iteration of every active instance in multi-workgroup mode: stamp -> LU -> solves -> Newton bits
+    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor)
+    {
+        size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
+        {
+            hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top), lds);
+            if(e != hipSuccess) return e;
+        }
+        int const B = V.batch, T = V.n_waves * 64;
+        int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
+        hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
+        hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
+        if(do_factor)
+        {
+            hipLaunchKernelGGL(k_m2_factor_parts, dim3(V.n_parts, B), dim3(T), lds, st, V);
+            for(int l = 0; l < V.n_top_levels; ++l)
+                hipLaunchKernelGGL(k_m2_factor_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
+        }
+        hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
+        hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 0);
+        for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 0);
+        for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 1);
+        hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 1);
+        hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);
+        return hipGetLastError();
+    }
+
+    hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt)
+    {
+        int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
+        hipLaunchKernelGGL(k_m2_companion, dim3(G, V.batch), dim3(256), 0, st, V, dt);
         return hipGetLastError();
     }
 

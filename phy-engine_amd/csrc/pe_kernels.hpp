@@ -15,4 +15,7 @@ namespace pe
     hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse_factor);
     hipError_t launch_dc_point(hipStream_t st, DevView const& V, int mode);
     hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor);
+    // multi-workgroup mode (V.n_parts > 1)
+    hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt);
+    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor);
 }  // namespace pe

@@ -90,6 +90,55 @@ namespace pe
         for(int b = 0; b < V.batch; ++b) dc_point(SerialTeam{V.n_waves}, V, b, mode, mem.data());
         return hipSuccess;
     }
+    hipError_t launch_m2_companion(hipStream_t, DevView const& V, double dt)
+    {
+        for(int b = 0; b < V.batch; ++b)
+            if(V.active[b]) companion_update(SerialTeam{1}, V, b, dt);
+        return hipSuccess;
+    }
+    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor)
+    {
+        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        SerialTeam tm{V.n_waves};
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
+            double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
+            for(int r = 0; r < V.rows; ++r) xp[r] = x[r];
+            eval_devices(tm, V, b, mode, t, last_step);
+            V.flags[b] = 0;
+            stamp(tm, V, b);
+            if(do_factor)
+            {
+                for(int q = 0; q < V.n_parts; ++q)
+                    if(!factor_part(tm, V, b, q, mem.data())) V.flags[b] |= 4;
+                for(int l = 0; l < V.n_top_levels; ++l)
+                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
+                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), false)) V.flags[b] |= 4;
+            }
+            for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
+            for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
+            for(int l = 0; l < V.n_top_levels; ++l)
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.max_p);
+            for(int l = V.n_top_levels - 1; l >= 0; --l)
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.max_p);
+            for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
+            for(int k = 0; k < V.rows; ++k)
+            {
+                int const r = V.col_src[k];
+                double const xn = w[k];
+                x[r] = xn;
+                if(!(std::fabs(xn) <= 1.7976931348623157e308)) V.flags[b] |= 1;
+                bool const node = r < V.n_nodes;
+                double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * std::fmax(std::fabs(xn), std::fabs(xp[r]));
+                if(!(std::fabs(xn - xp[r]) <= tol)) V.flags[b] |= 2;
+            }
+        }
+        return hipSuccess;
+    }
     hipError_t launch_factor_solve(hipStream_t, DevView const& V, bool do_factor)
     {
         std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);

@@ -189,3 +189,43 @@ def test_dc_then_tr_switches_symbolic(eng, oracle_mod):
     eng.analyze_dc(pe.ffi.MODE_TROP)
     eng.analyze_tr(1e-6, 50)
     assert max_err(eng.solution()[0], o.x, *LIN) <= 1.0
+
+
+# ---- multi-workgroup schedule (one circuit spread over several workgroups; knob PHY_ENGINE_HIP_PARTS) ----------
+@pytest.mark.parametrize("name,tol,parts", [("mesh32_nl", NL, 6), ("mesh32_lin", LIN, 16), ("ladder_c1", LIN, 4), ("mesh100_nl", NL, 1),
+                                            ("mesh100_nl", NL, 13), ("bridge_c2", NL, 2)])
+def test_golden_parity_multi_workgroup(name, tol, parts, monkeypatch):
+    """Same goldens through the parts + top-levels schedule (pe_engine.cpp run_m2_tr) and, for M10k, through the
+    single-workgroup kernel (parts = 1) that batch = 1 no longer selects by itself."""
+    monkeypatch.setenv("PHY_ENGINE_HIP_PARTS", str(parts))
+    e = pe.ffi.Engine(device=0)
+    try:
+        meta, gx, deck = golden(name)
+        snaps, trace, fail = run_engine_case(e, meta, deck)
+        assert fail == -1 and len(snaps) == len(gx)
+        assert max_err(snaps[:, 0, :], gx, *tol) <= 1.0
+        assert list(trace) == meta["newton_iters"]
+    finally:
+        e.close()
+
+
+def test_multi_workgroup_batch_matches_single_workgroup(monkeypatch):
+    """A 4-instance M10k sweep: the multi-workgroup schedule (auto for batch <= 128) and the single-workgroup
+    kernel agree to rounding (different elimination trees => different summation order, so not bitwise)."""
+    deck = pe.deck.rc_mesh(100, 100, 1, True)
+    out = []
+    for parts in (1, 0):
+        if parts:
+            monkeypatch.setenv("PHY_ENGINE_HIP_PARTS", str(parts))
+        else:
+            monkeypatch.delenv("PHY_ENGINE_HIP_PARTS", raising=False)
+        e = pe.ffi.Engine(device=0)
+        e.set_options(g_min=0.0)
+        e.load_deck(deck, batch=4)
+        e.reset()
+        e.update_param(pe.ffi.VAC, 0, 0, [2.0, 3.0, 1.0, 2.5])   # amplitude per instance
+        e.analyze_tr(1e-10, 10)
+        out.append((e.solution().copy(), e.state()["iters"].copy()))
+        e.close()
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-9 * np.max(np.abs(out[0][0]))

@@ -123,13 +123,16 @@ def emu_lib():
     return os.path.join(emu, "libpe_hip_emu.so")
 
 
-@pytest.mark.parametrize("name", ["rc_step", "rlc_series_vl_trop", "diode_op", "bridge_c2", "mesh32_nl_seed2", "ladder_c1"])
-def test_front_code_indexing_under_host_emulation(emu_lib, name):
+@pytest.mark.parametrize("name,parts", [("rc_step", 1), ("rlc_series_vl_trop", 1), ("diode_op", 1), ("bridge_c2", 1), ("mesh32_nl_seed2", 1),
+                                        ("ladder_c1", 1), ("mesh32_nl_seed2", 6), ("mesh32_lin", 16), ("ladder_c1", 4)])
+def test_front_code_indexing_under_host_emulation(emu_lib, name, parts):
     """Runs pe_front.hpp + pe_engine.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
+    parts > 1 = the multi-workgroup schedule (level-1 cut + top levels, one launch per phase).
     This validates indexing/orchestration only; the parity proper is tests/test_gpu_parity.py on the MI355X."""
     code = f"""
 import os, sys
 os.environ['PE_HIP_LIB'] = {emu_lib!r}
+os.environ['PHY_ENGINE_HIP_PARTS'] = '{parts}'
 sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
 import numpy as np
 from parity_common import *
