@@ -171,7 +171,12 @@ namespace
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
         V.wave_p = so.wave_p;
-        V.lds_slot = static_cast<int>(S.wave_panel_doubles);
+        // a wavefront's slot: its largest pivot panels, and room for whole small fronts (m x m, pe_front.hpp FULL mode)
+        {
+            long long const share = (h->lds_limit / 8 - 160) / std::max(1, so.n_waves);
+            long long const full = std::min<long long>(static_cast<long long>(so.wave_m) * so.wave_m, share);
+            V.lds_slot = static_cast<int>(std::max(S.wave_panel_doubles, batch >= 384 ? std::min<long long>(full, so.panel_doubles / std::max(1, so.n_waves)) : full));
+        }
         V.lds_sslot = so.wave_m + so.wave_p * so.wave_p + 64;  // t[m] + staged p x p block + partial sums of one wavefront
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
@@ -236,6 +241,8 @@ namespace
         while(static_cast<long long>(so.n_waves) * so.wave_p * 2 * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
         so.panel_doubles = std::min<long long>(lds_doubles, static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m);
+        // an oversubscribing sweep keeps 4 (>= 768 instances) or 2 workgroups per CU: their share of the 160 KB
+        if(batch >= 768) so.panel_doubles = std::max<long long>(so.panel_doubles, lds_doubles / 4 - 8);
         return so;
     }
 

@@ -317,51 +317,83 @@ namespace pe
     // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
     // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
     template <class Team>
-    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s, double* lds, bool profile)
+    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, bool profile)
     {
+        int const s = tm.uniform(s_in);
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
         double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
         double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
         double* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        // FULL mode (the whole m x m front fits the team's LDS region, column major, ld m): the children's update
+        // matrices stream in once, unconditionally and coalesced, and land by LDS scatter -- one memory round trip per
+        // child instead of index-dependent pulls.  PANEL mode (large fronts): only the pivot panels live in LDS and the
+        // Schur block pulls the children's entries tile by tile through the inverse maps.
+        bool const full = m * m <= cap;
+        int const ldu = full ? m : p;
+        int const nlds = full ? m * m : m * p + p * u;
         double* Lp = lds;
         double* Up = lds + m * p;
         int const T = tm.size(), t0 = tm.tid();
         long long const ck0 = tm.clock();
         int const ch0 = V.f_child_ptr[s], ch1 = V.f_child_ptr[s + 1];
-        for(int i = t0; i < m * p + p * u; i += T) lds[i] = 0.0;
+        for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
         tm.sync();
         for(int ch = ch0; ch < ch1; ++ch)
         {
-            // entries of the child's update matrix that land in this front's pivot rows / columns
             int const c = V.f_child[ch];
             int const uc = V.f_u[c];
             double const* Sc = arena + V.f_sptr[c];
             int const* rel = V.f_rel + V.f_rows_ptr[c];
             float const rcp = 1.0f / static_cast<float>(uc);
             int const n = uc * uc;
-            for(int base = t0; base < n; base += 4 * T)
+            if(full)
             {
-                double v[4];
-                int d[4];
-#pragma unroll
-                for(int q = 0; q < 4; ++q)
+                for(int base = t0; base < n; base += 4 * T)
                 {
-                    int const idx = base + q * T;
-                    d[q] = -1;
-                    v[q] = 0.0;
-                    if(idx < n)
-                    {
-                        int const j = fdiv(idx, rcp), i = idx - j * uc;
-                        int const ri = rel[i], rj = rel[j];
-                        if(rj < p) d[q] = ri + rj * m;
-                        else if(ri < p)
-                            d[q] = m * p + ri + (rj - p) * p;
-                        if(d[q] >= 0) v[q] = Sc[idx];
-                    }
-                }
+                    double v[4];
+                    int d[4];
 #pragma unroll
-                for(int q = 0; q < 4; ++q)
-                    if(d[q] >= 0) lds[d[q]] += v[q];
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        int const idx = base + q * T;
+                        bool const in = idx < n;
+                        int const ix = in ? idx : 0;
+                        v[q] = Sc[ix];
+                        int const j = fdiv(ix, rcp), i = ix - j * uc;
+                        d[q] = in ? rel[i] + rel[j] * m : -1;
+                    }
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                        if(d[q] >= 0) lds[d[q]] += v[q];
+                }
+            }
+            else
+            {
+                // entries of the child's update matrix that land in this front's pivot rows / columns
+                for(int base = t0; base < n; base += 4 * T)
+                {
+                    double v[4];
+                    int d[4];
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        int const idx = base + q * T;
+                        d[q] = -1;
+                        v[q] = 0.0;
+                        if(idx < n)
+                        {
+                            int const j = fdiv(idx, rcp), i = idx - j * uc;
+                            int const ri = rel[i], rj = rel[j];
+                            if(rj < p) d[q] = ri + rj * m;
+                            else if(ri < p)
+                                d[q] = m * p + ri + (rj - p) * p;
+                            if(d[q] >= 0) v[q] = Sc[idx];
+                        }
+                    }
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                        if(d[q] >= 0) lds[d[q]] += v[q];
+                }
             }
             tm.sync();
         }
@@ -372,7 +404,7 @@ namespace pe
             double const v = a[V.asm_slot[e]];
             if(c < p) Lp[r + c * m] += v;
             else
-                Up[r + (c - p) * p] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
+                Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
         }
         tm.sync();
         long long const ck1 = tm.clock();
@@ -428,7 +460,7 @@ namespace pe
                     {
                         // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
                         int const jc = q - nrows;
-                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * p + k0;
+                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * ldu + k0;
 #pragma unroll
                         for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
 #pragma unroll
@@ -485,10 +517,10 @@ namespace pe
                                 int const tc = q / trU, tr = q - tc * trU;
                                 row0 = r0 + 16 * tr;
                                 int const col0 = 16 * tc;
-                                C = Up + row0 + col0 * p;
-                                ldc = p;
-                                B = Up + k0 + col0 * p;
-                                ldb = p;
+                                C = Up + row0 + col0 * ldu;
+                                ldc = ldu;
+                                B = Up + k0 + col0 * ldu;
+                                ldb = ldu;
                                 mr = p - row0 < 16 ? p - row0 : 16;
                                 nc = u - col0 < 16 ? u - col0 : 16;
                             }
@@ -519,29 +551,44 @@ namespace pe
                         int const i0 = 16 * ti, j0 = 16 * tj;
                         int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
                         auto acc = tm.tile_zero();
-                        for(int ch = ch0; ch < ch1; ++ch)
+                        if(full) acc = tm.tile_load(Up + p + i0 + j0 * ldu, ldu, mr, nc, lane);
+                        else
                         {
-                            int const* inv = V.f_inv + V.f_inv_off[ch] + p;
-                            int const cc = V.f_child[ch];
-                            int const uc = V.f_u[cc];
-                            double const* Sc = arena + V.f_sptr[cc];
-                            tm.tile_foreach(acc, lane,
-                                            [&](int r, int c, double& v)
-                                            {
-                                                if(r < mr && c < nc)
+                            for(int ch = ch0; ch < ch1; ++ch)
+                            {
+                                int const* inv = V.f_inv + V.f_inv_off[ch] + p;
+                                int const cc = V.f_child[ch];
+                                int const uc = V.f_u[cc];
+                                double const* Sc = arena + V.f_sptr[cc];
+                                tm.tile_foreach(acc, lane,
+                                                [&](int r, int c, double& v)
                                                 {
-                                                    int const ci = inv[i0 + r], cj = inv[j0 + c];
-                                                    if(ci >= 0 && cj >= 0) v += Sc[ci + cj * uc];
-                                                }
-                                            });
+                                                    if(r < mr && c < nc)
+                                                    {
+                                                        int const ci = inv[i0 + r], cj = inv[j0 + c];
+                                                        if(ci >= 0 && cj >= 0) v += Sc[ci + cj * uc];
+                                                    }
+                                                });
+                            }
                         }
-                        tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * p, p, mr, nc, p, lane);
+                        tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
                         tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
                     }
                 });
         }
         double* Lg = fac + V.f_lptr[s];
-        for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
+        if(full)
+        {
+            for(int i = t0; i < m * p; i += T) Lg[i] = lds[i];
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * u; idx += T)
+            {
+                int const j = fdiv(idx, rp), r = idx - j * p;
+                Lg[m * p + idx] = Up[r + j * ldu];
+            }
+        }
+        else
+            for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
         tm.sync();
         return true;
     }
@@ -558,8 +605,9 @@ namespace pe
             {
                 auto wt = tm.wave_team(lane);
                 double* slot = lds + static_cast<long long>(w) * V.lds_slot;
-                for(int q = wp[w]; q < wp[w + 1]; ++q)
-                    if(!front_factor(wt, V, b, V.wave_list[q], slot, false))
+                int const q1 = tm.uniform(wp[w + 1]);
+                for(int q = tm.uniform(wp[w]); q < q1; ++q)
+                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, false))
                     {
                         fail = 1;
                         break;
@@ -568,7 +616,7 @@ namespace pe
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
         for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q)
-            if(!front_factor(tm, V, b, V.coop_list[q], lds, true)) return false;
+            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, true)) return false;
         if(V.prof && tm.tid() == 0 && part == 0)
         {
             V.prof[b * 8 + 1] += c1 - c0;
@@ -618,8 +666,9 @@ namespace pe
     }
 
     template <class Team>
-    PE_DEV void front_forward(Team const& tm, DevView const& V, int b, int s, double* lds, int cap_m, int cap_p)
+    PE_DEV void front_forward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_p)
     {
+        int const s = tm.uniform(s_in);
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
         int const T = tm.size(), t0 = tm.tid();
         double* w = V.w + static_cast<long long>(b) * V.rows;
@@ -675,8 +724,9 @@ namespace pe
     }
 
     template <class Team>
-    PE_DEV void front_backward(Team const& tm, DevView const& V, int b, int s, double* lds, int cap_m, int cap_p)
+    PE_DEV void front_backward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_p)
     {
+        int const s = tm.uniform(s_in);
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
         int const T = tm.size(), t0 = tm.tid();
         double* w = V.w + static_cast<long long>(b) * V.rows;
@@ -736,7 +786,8 @@ namespace pe
             {
                 auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = wp[wv]; q < wp[wv + 1]; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+                int const q1 = tm.uniform(wp[wv + 1]);
+                for(int q = tm.uniform(wp[wv]); q < q1; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
             });
         tm.sync();
         for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
@@ -753,7 +804,8 @@ namespace pe
             {
                 auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
-                for(int q = wp[wv + 1] - 1; q >= wp[wv]; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+                int const q0 = tm.uniform(wp[wv]);
+                for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
             });
         tm.sync();
     }

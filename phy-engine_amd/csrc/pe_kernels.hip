@@ -23,6 +23,10 @@ namespace pe
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __device__ __forceinline__ int lanes() const { return 64; }
+        // a value that is the same in every lane of the wavefront but that the compiler cannot prove uniform (anything
+        // derived from the wavefront's index): moved to an SGPR so that the loads it indexes become scalar loads and
+        // the address arithmetic leaves the vector ALU
+        __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
         __device__ __forceinline__ long long clock() const { return static_cast<long long>(wall_clock64()); }
 
         // LU (no pivoting) of a kb x kb block (kb <= 8) held one entry per lane: lane l <-> (row l&7, col l>>3).
@@ -50,8 +54,11 @@ namespace pe
         }
 
         // ---- 16 x 16 fp64 tiles on the matrix core: v_mfma_f64_16x16x4_f64.
-        // Lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]; the accumulator register r of lane l is
-        // D[row = (l>>4) + 4r][col = l&15]  (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").
+        // The instruction takes A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] from lane l and keeps
+        // D[(l>>4) + 4r][l&15] in accumulator register r (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").
+        // The tiles here are held TRANSPOSED (the instruction computes C^T -= B^T A^T, i.e. the operands swap seats):
+        // lane l owns C[row = l&15][col = (l>>4) + 4r], so the 16 lanes of a quarter-wave touch 16 consecutive rows of
+        // a column-major matrix -- 128-byte segments in HBM (Schur blocks) and conflict-free LDS banks (panels).
         using v4d = __attribute__((ext_vector_type(4))) double;
         struct Acc
         {
@@ -61,22 +68,22 @@ namespace pe
         __device__ __forceinline__ Acc tile_load(double const* C, int ldc, int mr, int nc, int lane) const
         {
             Acc a;
-            int const col = lane & 15, rb = lane >> 4;
+            int const row = lane & 15, cb = lane >> 4;
 #pragma unroll
             for(int r = 0; r < 4; ++r)
             {
-                int const row = rb + 4 * r;
+                int const col = cb + 4 * r;
                 a.v[r] = (row < mr && col < nc) ? C[row + col * ldc] : 0.0;
             }
             return a;
         }
         __device__ __forceinline__ void tile_store(Acc const& a, double* C, int ldc, int mr, int nc, int lane) const
         {
-            int const col = lane & 15, rb = lane >> 4;
+            int const row = lane & 15, cb = lane >> 4;
 #pragma unroll
             for(int r = 0; r < 4; ++r)
             {
-                int const row = rb + 4 * r;
+                int const col = cb + 4 * r;
                 if(row < mr && col < nc) C[row + col * ldc] = a.v[r];
             }
         }
@@ -89,18 +96,18 @@ namespace pe
                 int const k = kk + kq;
                 double const av = (k < kd && ij < mr) ? -A[ij + k * lda] : 0.0;
                 double const bv = (k < kd && ij < nc) ? B[k + ij * ldb] : 0.0;
-                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, a.v, 0, 0, 0);
+                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, a.v, 0, 0, 0);
             }
         }
         template <class F>
         __device__ __forceinline__ void tile_foreach(Acc& a, int lane, F&& f) const
         {
-            int const col = lane & 15, rb = lane >> 4;
+            int const row = lane & 15, cb = lane >> 4;
 #pragma unroll
             for(int r = 0; r < 4; ++r)
             {
                 double t = a.v[r];
-                f(rb + 4 * r, col, t);
+                f(row, cb + 4 * r, t);
                 a.v[r] = t;
             }
         }
@@ -134,7 +141,7 @@ namespace pe
         template <class F>
         __device__ __forceinline__ void for_each_wave(F&& body) const
         {
-            body(static_cast<int>(threadIdx.x) >> 6, static_cast<int>(threadIdx.x) & 63, 64);
+            body(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6), static_cast<int>(threadIdx.x) & 63, 64);
         }
         __device__ __forceinline__ WaveTeam wave_team(int lane) const
         {
@@ -239,7 +246,7 @@ namespace pe
         if(!V.active[b]) return;
         HipTeam tm;
         int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(!front_factor(tm, V, b, s, pe_lds, false) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, false) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)

@@ -13,6 +13,7 @@ namespace pe
         int nw;
         SerialTeam wave_team(int) const { return SerialTeam{1}; }
         int tid() const { return 0; }
+        int uniform(int v) const { return v; }
         int size() const { return 1; }
         void sync() const {}
         int sync_or(int v) const { return v; }
@@ -117,7 +118,7 @@ namespace pe
                     if(!factor_part(tm, V, b, q, mem.data())) V.flags[b] |= 4;
                 for(int l = 0; l < V.n_top_levels; ++l)
                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), false)) V.flags[b] |= 4;
+                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, false)) V.flags[b] |= 4;
             }
             for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
             for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
