@@ -134,6 +134,13 @@ namespace
     }
 
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
+    // test knob: choose the launch geometry as if the batch had this many instances
+    int geometry_batch(int batch)
+    {
+        char const* v = std::getenv("PHY_ENGINE_HIP_GEOMETRY_BATCH");
+        return v && *v ? std::max(1, std::atoi(v)) : batch;
+    }
+
     int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic const& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
     {
         V.nfronts = S.nfronts;
@@ -166,17 +173,12 @@ namespace
         if(V.n_top_levels > 16) return fail(h, PE_HIP_ERR_INTERNAL, "assembly tree has more than 16 top levels");
         for(int l = 0; l < V.n_top_levels; ++l) V.top_cnt[l] = S.top_ptr[l + 1] - S.top_ptr[l];
         V.n_waves = so.n_waves;
-        V.high_occupancy = batch >= 384 ? 1 : 0;
+        V.high_occupancy = geometry_batch(batch) >= 384 ? 1 : 0;
         V.wave_m = so.wave_m;
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
         V.wave_p = so.wave_p;
-        // a wavefront's slot: its largest pivot panels, and room for whole small fronts (m x m, pe_front.hpp FULL mode)
-        {
-            long long const share = (h->lds_limit / 8 - 160) / std::max(1, so.n_waves);
-            long long const full = std::min<long long>(static_cast<long long>(so.wave_m) * so.wave_m, share);
-            V.lds_slot = static_cast<int>(std::max(S.wave_panel_doubles, batch >= 384 ? std::min<long long>(full, so.panel_doubles / std::max(1, so.n_waves)) : full));
-        }
+        V.lds_slot = so.wave_m * so.wave_m;  // a wavefront's slot holds its fronts whole (order <= wave_m: pe_front.hpp FULL mode)
         V.lds_sslot = so.wave_m + so.wave_p * so.wave_p + 64;  // t[m] + staged p x p block + partial sums of one wavefront
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
@@ -193,16 +195,19 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
-    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch, int rows)
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows)
     {
+        int const batch = geometry_batch(batch_in);
         pe::SymbolicOptions so{};
         // workgroup geometry by batch size (measured on MI355X, profiles/): few instances -> one big workgroup per CU;
         // a sweep that oversubscribes the 256 CUs -> smaller workgroups, 2-4 resident per CU
         if(batch >= 768)
         {
             so.n_waves = 4;
-            so.wave_m = 32;
-            so.max_pivots = 32;
+            so.wave_m = 35;
+            so.wave_p = 32;
+            so.absorb_m = 35;
+            so.max_pivots = 48;
         }
         else if(batch >= 384)
         {
@@ -236,13 +241,14 @@ namespace
         so.n_parts = std::clamp(env_int("PHY_ENGINE_HIP_PARTS", so.n_parts), 1, 64);
         so.part_cut = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_PART_CUT_X10", static_cast<int>(so.part_cut * 10.0)));
         so.wave_p = std::min(so.wave_p, so.max_pivots);
-        long long const lds_doubles = h->lds_limit / 8 - 160;  // leave room for the static LDS of __syncthreads_or & co.
-        // a wave front needs p * (m + u) <= wave_p * 2 * wave_m doubles of LDS; keep all wavefronts' slots within the limit
-        while(static_cast<long long>(so.n_waves) * so.wave_p * 2 * so.wave_m > lds_doubles && so.wave_m > 8) so.wave_m -= 4;
+        // LDS share of one workgroup: the 128-VGPR kernels keep 16 wavefronts per CU resident (16 / n_waves workgroups)
+        int const resident = std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", batch >= 384 ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
+        long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
+        // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
+        while(static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m > lds_doubles && so.wave_m > 8) --so.wave_m;
+        so.wave_p = std::min(so.wave_p, so.wave_m);
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
-        so.panel_doubles = std::min<long long>(lds_doubles, static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m);
-        // an oversubscribing sweep keeps 4 (>= 768 instances) or 2 workgroups per CU: their share of the 160 KB
-        if(batch >= 768) so.panel_doubles = std::max<long long>(so.panel_doubles, lds_doubles / 4 - 8);
+        so.panel_doubles = lds_doubles;
         return so;
     }
 
@@ -266,6 +272,26 @@ namespace
             for(int s = 0; s < S.nfronts; ++s) ++nk[S.f_kind[s]];
             std::fprintf(stderr, "[pe_hip] schedule: %d fronts (%d wave, %d cooperative, %d top), %d parts, %d top levels\n", S.nfronts, nk[0], nk[1],
                          nk[2], S.n_parts, static_cast<int>(S.top_ptr.size()) - 1);
+            for(int kind = 0; kind < 2; ++kind)
+            {
+                long long cnt[3]{}, su2[3]{}, spanel[3]{};
+                long long const cap = kind == 0 ? std::max<long long>(S.wave_panel_doubles, 1) : so.panel_doubles;
+                for(int s = 0; s < S.nfronts; ++s)
+                {
+                    if(S.f_kind[s] != kind) continue;
+                    long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
+                    int const nch = S.f_child_ptr[s + 1] - S.f_child_ptr[s];
+                    int const mode = m * m <= cap ? 0 : (nch == 1 && S.f_u[S.f_child[S.f_child_ptr[s]]] == m ? 2 : 1);
+                    ++cnt[mode];
+                    su2[mode] += u * u;
+                    spanel[mode] += m * p + p * u;
+                }
+                std::fprintf(stderr, "[pe_hip]   %s fronts (cap ~%lld doubles): whole %lld (S %lld, panels %lld) | panel+pull %lld (S %lld, panels %lld) | chain link %lld (S %lld, panels %lld)\n",
+                             kind == 0 ? "wave" : "cooperative", cap, cnt[0], su2[0], spanel[0], cnt[1], su2[1], spanel[1], cnt[2], su2[2], spanel[2]);
+            }
+            if(dump[1] == '2')
+                for(int s = 0; s < S.nfronts; ++s)
+                    if(S.f_kind[s] == 1) std::fprintf(stderr, "[pe_hip]   coop front %d: %dx%d children %d\n", s, S.f_p[s] + S.f_u[s], S.f_p[s], S.f_child_ptr[s + 1] - S.f_child_ptr[s]);
             for(std::size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
             {
                 std::fprintf(stderr, "[pe_hip]   top level %zu:", l);
@@ -525,6 +551,8 @@ int pe_hip_create(int device, pe_hip_engine** out)
     }
     int lds = 0;
     if(hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0) h->lds_limit = lds;
+    // test knob: pretend the LDS is smaller (forces the large-front PANEL / chain paths on small circuits)
+    if(char const* v = std::getenv("PHY_ENGINE_HIP_LDS_BYTES"); v && *v) h->lds_limit = std::clamp(std::atoi(v), 8192, h->lds_limit);
     h->opt.refactor_every_solve = 1;
     *out = h.release();
     return PE_HIP_OK;

@@ -328,14 +328,15 @@ namespace pe
         // matrices stream in once, unconditionally and coalesced, and land by LDS scatter -- one memory round trip per
         // child instead of index-dependent pulls.  PANEL mode (large fronts): only the pivot panels live in LDS and the
         // Schur block pulls the children's entries tile by tile through the inverse maps.
+        int const ch0 = V.f_child_ptr[s], ch1 = V.f_child_ptr[s + 1];
         bool const full = m * m <= cap;
+        bool const chain = !full && ch1 - ch0 == 1 && V.f_u[V.f_child[ch0]] == m;  // then f_rel of the child is the identity
         int const ldu = full ? m : p;
         int const nlds = full ? m * m : m * p + p * u;
         double* Lp = lds;
         double* Up = lds + m * p;
         int const T = tm.size(), t0 = tm.tid();
         long long const ck0 = tm.clock();
-        int const ch0 = V.f_child_ptr[s], ch1 = V.f_child_ptr[s + 1];
         for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
         tm.sync();
         for(int ch = ch0; ch < ch1; ++ch)
@@ -346,7 +347,28 @@ namespace pe
             int const* rel = V.f_rel + V.f_rows_ptr[c];
             float const rcp = 1.0f / static_cast<float>(uc);
             int const n = uc * uc;
-            if(full)
+            if(chain)
+            {
+                // the child's update matrix IS this front (a long separator split into links): straight copies
+                stage_copy<4>(Lp, Sc, m * p, t0, T);
+                float const rp = 1.0f / static_cast<float>(p);
+                for(int base = t0; base < p * u; base += 4 * T)
+                {
+                    double v[4];
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                    {
+                        int const idx = base + q * T;
+                        int const ix = idx < p * u ? idx : 0;
+                        int const cc = fdiv(ix, rp), r = ix - cc * p;
+                        v[q] = Sc[r + (p + cc) * m];
+                    }
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                        if(base + q * T < p * u) Up[base + q * T] = v[q];
+                }
+            }
+            else if(full)
             {
                 for(int base = t0; base < n; base += 4 * T)
                 {
@@ -552,6 +574,8 @@ namespace pe
                         int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
                         auto acc = tm.tile_zero();
                         if(full) acc = tm.tile_load(Up + p + i0 + j0 * ldu, ldu, mr, nc, lane);
+                        else if(chain)
+                            acc = tm.tile_load(arena + V.f_sptr[V.f_child[ch0]] + (p + i0) + static_cast<long long>(p + j0) * m, m, mr, nc, lane);
                         else
                         {
                             for(int ch = ch0; ch < ch1; ++ch)
@@ -698,13 +722,8 @@ namespace pe
         tm.for_each_wave(
             [&](int w, int lane, int NLw)
             {
-                if(w != 0) return;  // wavefront 0 runs the dependent chain without workgroup barriers
-                for(int k = 0; k + 1 < p; ++k)
-                {
-                    double const yk = t[k];
-                    for(int i = k + 1 + lane; i < p; i += NLw) t[i] -= Lb[i + k * p] * yk;
-                    tm.wave_fence();
-                }
+                if(w != 0) return;  // wavefront 0 runs the dependent chain in registers, without workgroup barriers
+                tm.tri_lower_unit(t, Lb, p, p, lane);
             });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
@@ -764,13 +783,7 @@ namespace pe
             [&](int w, int lane, int NLw)
             {
                 if(w != 0) return;
-                for(int k = p - 1; k >= 0; --k)
-                {
-                    double const xk = t[k] / Ub[k + k * p];
-                    for(int i = lane; i < k; i += NLw) t[i] -= Ub[i + k * p] * xk;
-                    if(lane == 0) t[k] = xk;
-                    tm.wave_fence();
-                }
+                tm.tri_upper(t, Ub, p, p, lane);
             });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];

@@ -53,6 +53,65 @@ namespace pe
             return bad;
         }
 
+        // broadcast lane k's value (k wavefront-uniform): v_readlane, no LDS round trip
+        __device__ __forceinline__ double bcast(double v, int k) const
+        {
+            int const lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+            int const hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+            return __hiloint2double(hi, lo);
+        }
+        // Triangular solves of the triangular-solve phase, p <= 64, one wavefront: lane i owns t[i]; the dependent chain
+        // runs on lane broadcasts, the matrix columns (LDS, independent of the chain) are fetched four steps ahead.
+        // L y = t, unit lower triangle of Lb (ld)
+        __device__ __forceinline__ void tri_lower_unit(double* t, double const* Lb, int ld, int p, int lane) const
+        {
+            bool const own = lane < p;
+            double ti = own ? t[lane] : 0.0;
+            for(int k0 = 0; k0 + 1 < p; k0 += 4)
+            {
+                double l[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q) l[q] = (own && k0 + q < p) ? Lb[lane + (k0 + q) * ld] : 0.0;
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    int const k = k0 + q;
+                    double const yk = bcast(ti, k & 63);
+                    if(lane > k) ti -= l[q] * yk;
+                }
+            }
+            if(own) t[lane] = ti;
+        }
+        // U x = t, upper triangle of Ub (ld) with its diagonal
+        __device__ __forceinline__ void tri_upper(double* t, double const* Ub, int ld, int p, int lane) const
+        {
+            bool const own = lane < p;
+            double ti = own ? t[lane] : 0.0;
+            double const d = own ? Ub[lane + lane * ld] : 1.0;
+            double const r = 1.0 / d;  // off the chain; the quotient below is refined to the correctly rounded t / d
+            for(int k0 = p - 1; k0 >= 0; k0 -= 4)
+            {
+                double uc[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q) uc[q] = (k0 - q >= 0 && lane < k0 - q) ? Ub[lane + (k0 - q) * ld] : 0.0;
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    int const k = k0 - q;
+                    if(k >= 0)
+                    {
+                        double qv = ti * r;
+                        double const e = __builtin_fma(-qv, d, ti);
+                        qv = __builtin_fma(e, r, qv);
+                        double const xk = bcast(qv, k);
+                        if(lane == k) ti = xk;
+                        if(lane < k) ti -= uc[q] * xk;
+                    }
+                }
+            }
+            if(own) t[lane] = ti;
+        }
+
         // ---- 16 x 16 fp64 tiles on the matrix core: v_mfma_f64_16x16x4_f64.
         // The instruction takes A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] from lane l and keeps
         // D[(l>>4) + 4r][l&15] in accumulator register r (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").

@@ -41,6 +41,19 @@ namespace pe
             }
             return 0;
         }
+        void tri_lower_unit(double* t, double const* Lb, int ld, int p, int) const
+        {
+            for(int k = 0; k + 1 < p; ++k)
+                for(int i = k + 1; i < p; ++i) t[i] -= Lb[i + k * ld] * t[k];
+        }
+        void tri_upper(double* t, double const* Ub, int ld, int p, int) const
+        {
+            for(int k = p - 1; k >= 0; --k)
+            {
+                t[k] = t[k] / Ub[k + k * ld];
+                for(int i = 0; i < k; ++i) t[i] -= Ub[i + k * ld] * t[k];
+            }
+        }
         // plain-loop stand-in for the 16 x 16 matrix-core tiles
         struct Acc
         {

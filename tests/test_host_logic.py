@@ -124,15 +124,19 @@ def emu_lib():
 
 
 @pytest.mark.parametrize("name,parts", [("rc_step", 1), ("rlc_series_vl_trop", 1), ("diode_op", 1), ("bridge_c2", 1), ("mesh32_nl_seed2", 1),
-                                        ("ladder_c1", 1), ("mesh32_nl_seed2", 6), ("mesh32_lin", 16), ("ladder_c1", 4)])
+                                        ("ladder_c1", 1), ("mesh32_nl_seed2", 6), ("mesh32_lin", 16), ("ladder_c1", 4),
+                                        ("mesh32_nl_seed2", -1), ("mesh32_lin", -4), ("ladder_c1", -1)])
 def test_front_code_indexing_under_host_emulation(emu_lib, name, parts):
     """Runs pe_front.hpp + pe_engine.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
-    parts > 1 = the multi-workgroup schedule (level-1 cut + top levels, one launch per phase).
+    parts > 1 = the multi-workgroup schedule (level-1 cut + top levels, one launch per phase); parts < 0 = the same
+    with a small LDS so that the large-front code paths are exercised too.
     This validates indexing/orchestration only; the parity proper is tests/test_gpu_parity.py on the MI355X."""
     code = f"""
 import os, sys
 os.environ['PE_HIP_LIB'] = {emu_lib!r}
-os.environ['PHY_ENGINE_HIP_PARTS'] = '{parts}'
+os.environ['PHY_ENGINE_HIP_PARTS'] = '{abs(parts)}'
+if {parts} < 0:   # a 12 KB LDS: fronts no longer fit whole, the pivot-panel / pull / chain-link paths run
+    os.environ['PHY_ENGINE_HIP_LDS_BYTES'] = '12288'
 sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
 import numpy as np
 from parity_common import *
