@@ -106,7 +106,8 @@ def single_circuit_numbers(pe, W, dt, device):
         if nonlinear:
             out["nl_newton_iters_per_s"] = st["newton_iters"] / (st["gpu_ms"] * 1e-3)
         eng.close()
-    out["note"] = "one workgroup (one CU) per circuit: latency-bound; linear_reuse_factor skips B_factor (stamp + triangular solves only)"
+    out["note"] = ("one circuit spread over parts x workgroups + top levels (multi-workgroup schedule, one launch per phase, host Newton "
+                   "loop): latency-bound; linear_reuse_factor skips B_factor (stamp + triangular solves only)")
     return out
 
 
@@ -213,7 +214,9 @@ def main():
                        "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_per_gpu": B,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_tr_steps", "bytes_per_newton_iter": bpi["iter"], "launches": st["n_launches"],
+                         "traffic": None,
+                         "kernel": "k_tr_steps" if info.get("n_parts", 1) <= 1 else "multi-workgroup schedule: k_m2_* (one launch per phase and tree level)",
+                         "bytes_per_newton_iter": bpi["iter"], "launches": st["n_launches"],
                          "avg_launch_ms": st["gpu_ms"] / max(1, st["n_launches"])},
             "reduce_ms": reduce_ms,
             "stats_checksum": float(np.sum(stats[0])),

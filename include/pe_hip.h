@@ -102,6 +102,10 @@ typedef struct pe_hip_info
     long long bytes_per_instance; /* resident HBM bytes per circuit instance */
     int n_r, n_c, n_l, n_v, n_i, n_d;
     int nonlinear;
+    int n_parts;      /* > 1: multi-workgroup schedule (one circuit spread over n_parts workgroups + top levels) */
+    int n_top_levels; /* launches of the top of the tree in that schedule */
+    int n_wavefronts; /* wavefronts per workgroup of the launch geometry chosen for this batch */
+    int lds_bytes;    /* dynamic LDS per workgroup */
 } pe_hip_info;
 
 typedef struct pe_hip_run_stats

@@ -94,6 +94,7 @@ namespace pe
         int wave_m, wave_p, max_m, max_p;
         int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)
         int lds_sslot;          // doubles of one wavefront's solve scratch
+        int lds_wave_stage{}, lds_coop_stage{};  // doubles of the staged block of a wavefront / of the workgroup in the triangular solves
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;

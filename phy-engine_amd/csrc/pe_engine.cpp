@@ -179,12 +179,14 @@ namespace
         V.max_p = so.max_pivots;
         V.wave_p = so.wave_p;
         V.lds_slot = so.wave_m * so.wave_m;  // a wavefront's slot holds its fronts whole (order <= wave_m: pe_front.hpp FULL mode)
-        V.lds_sslot = so.wave_m + so.wave_p * so.wave_p + 64;  // t[m] + staged p x p block + partial sums of one wavefront
+        V.lds_wave_stage = so.wave_m * so.wave_p;              // a wavefront stages the whole m x p panel of its (small) fronts
+        V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
+        V.lds_sslot = so.wave_m + V.lds_wave_stage + 64;       // t[m] + staged block + partial sums of one wavefront
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
             need = std::max(need, so.panel_doubles);
             need = std::max(need, static_cast<long long>(so.n_waves) * V.lds_sslot);
-            need = std::max(need, static_cast<long long>(V.max_m) + static_cast<long long>(V.max_p) * V.max_p + so.n_waves * 64);
+            need = std::max(need, static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
             V.lds_doubles = static_cast<int>(need + 2);
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
@@ -407,7 +409,7 @@ namespace
     }
 
     // one solve point of every instance whose status is OK; result[b] = iterations (> 0) or a negative status
-    int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, std::vector<int>& result, int& launches)
+    int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, bool do_factor, std::vector<int>& result, int& launches)
     {
         int const B = h->hc.batch;
         result.assign(B, 0);
@@ -421,7 +423,7 @@ namespace
         for(int it = 0; it < max_it && n_active > 0; ++it)
         {
             HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, true));
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor));
             ++launches;
             HIPCHK(h, hipMemcpyAsync(S.flags.data(), h->V.flags, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -453,6 +455,7 @@ namespace
         int rc = m2_pull(h, S);
         if(rc != PE_HIP_OK) return rc;
         int const B = h->hc.batch;
+        bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve;
         std::vector<int> res;
         for(int s = 0; s < nsteps; ++s)
         {
@@ -474,8 +477,15 @@ namespace
                     break;
                 }
             double const t = t_prev + dt;
-            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, res, launches);
+            // linear circuit, same dt as the last factorisation: stamp + triangular solves only
+            bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
+            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, !reuse, res, launches);
             if(rc != PE_HIP_OK) return rc;
+            if(may_reuse)
+            {
+                h->fact_valid = true;
+                h->fact_dt = dt;
+            }
             for(int b = 0; b < B; ++b)
             {
                 if(S.status[b] != PE_HIP_OK || res[b] == 0) continue;
@@ -501,7 +511,7 @@ namespace
         std::vector<double> ls(B);
         HIPCHK(h, hipMemcpy(ls.data(), h->V.last_step, B * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<int> res;
-        rc = m2_point(h, S, mode, S.t[0], ls[0], res, launches);
+        rc = m2_point(h, S, mode, S.t[0], ls[0], true, res, launches);
         if(rc != PE_HIP_OK) return rc;
         for(int b = 0; b < B; ++b)
         {
@@ -723,6 +733,10 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
         out->n_fronts = h->sym.nfronts;
         out->max_front = h->sym.max_m;
         out->tree_depth = h->sym.tree_depth;
+        out->n_parts = h->V.n_parts;
+        out->n_top_levels = h->V.n_top_levels;
+        out->n_wavefronts = h->V.n_waves;
+        out->lds_bytes = h->V.lds_doubles * 8;
         out->n_row_swaps = h->sym.n_row_swaps;
         out->factor_flops = h->sym.flops;
     }

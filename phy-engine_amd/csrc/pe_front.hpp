@@ -338,7 +338,22 @@ namespace pe
         int const T = tm.size(), t0 = tm.tid();
         long long const ck0 = tm.clock();
         for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
-        tm.sync();
+        tm.sync_lds();
+        // the entries of A owned by this front first: their loads do not depend on anything a previous front wrote, so
+        // they overlap with that front's stores still in flight
+        for(int e = V.f_asm_ptr[s] + t0; e < V.f_asm_ptr[s + 1]; e += T)
+        {
+            int const pos = V.asm_pos[e];
+            int const r = pos >> 16, c = pos & 0xffff;
+            double const v = a[V.asm_slot[e]];
+            if(c < p) Lp[r + c * m] += v;
+            else
+                Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
+        }
+        // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
+        if(ch1 > ch0) tm.sync();
+        else
+            tm.sync_lds();
         for(int ch = ch0; ch < ch1; ++ch)
         {
             int const c = V.f_child[ch];
@@ -350,7 +365,15 @@ namespace pe
             if(chain)
             {
                 // the child's update matrix IS this front (a long separator split into links): straight copies
-                stage_copy<4>(Lp, Sc, m * p, t0, T);
+                for(int base = t0; base < m * p; base += 4 * T)
+                {
+                    double v[4];
+#pragma unroll
+                    for(int q = 0; q < 4; ++q) v[q] = Sc[base + q * T < m * p ? base + q * T : 0];
+#pragma unroll
+                    for(int q = 0; q < 4; ++q)
+                        if(base + q * T < m * p) Lp[base + q * T] += v[q];
+                }
                 float const rp = 1.0f / static_cast<float>(p);
                 for(int base = t0; base < p * u; base += 4 * T)
                 {
@@ -365,7 +388,7 @@ namespace pe
                     }
 #pragma unroll
                     for(int q = 0; q < 4; ++q)
-                        if(base + q * T < p * u) Up[base + q * T] = v[q];
+                        if(base + q * T < p * u) Up[base + q * T] += v[q];
                 }
             }
             else if(full)
@@ -417,18 +440,8 @@ namespace pe
                         if(d[q] >= 0) lds[d[q]] += v[q];
                 }
             }
-            tm.sync();
+            tm.sync_lds();
         }
-        for(int e = V.f_asm_ptr[s] + t0; e < V.f_asm_ptr[s + 1]; e += T)
-        {
-            int const pos = V.asm_pos[e];
-            int const r = pos >> 16, c = pos & 0xffff;
-            double const v = a[V.asm_slot[e]];
-            if(c < p) Lp[r + c * m] += v;
-            else
-                Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
-        }
-        tm.sync();
         long long const ck1 = tm.clock();
         int const NW = tm.n_waves();
         constexpr int NB = 8;
@@ -613,7 +626,7 @@ namespace pe
         }
         else
             for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
-        tm.sync();
+        tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
         return true;
     }
 
@@ -689,8 +702,11 @@ namespace pe
         // caller combines: out[i] = init[i] - sum_c part[c * nrow + i]
     }
 
+    // LDS layout of the triangular-solve phase (one team): t[cap_m] | staged block [cap_stage] | partial sums [T].
+    // SMALL fronts (m <= 64 and the whole m x p panel fits the staging block) run entirely on one wavefront's
+    // registers after ONE round of loads; larger ones stage the p x p pivot block and finish with a team mat-vec.
     template <class Team>
-    PE_DEV void front_forward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_p)
+    PE_DEV void front_forward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_stage)
     {
         int const s = tm.uniform(s_in);
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
@@ -699,9 +715,13 @@ namespace pe
         double* arena = V.arena + static_cast<long long>(b) * V.arena_doubles;
         double const* Lg = V.factor + static_cast<long long>(b) * V.factor_doubles + V.f_lptr[s];
         double* t = lds;                              // [m]
-        double* Lb = lds + cap_m;                     // staged L11 [p x p, ld p]
-        double* part = Lb + cap_p * cap_p;            // [T]
+        double* Lb = lds + cap_m;                     // staged L11 [p x p, ld p] or the whole L panel [m x p, ld m]
+        double* part = Lb + cap_stage;                // [T]
+        bool const small = m <= 64 && m * p <= cap_stage;
+        int const ldb = small ? m : p;
         for(int i = t0; i < m; i += T) t[i] = i < p ? w[c0 + i] : 0.0;
+        if(small) stage_copy<4>(Lb, Lg, m * p, t0, T);
+        else
         {
             float const rp = 1.0f / static_cast<float>(p);
             for(int idx = t0; idx < p * p; idx += T)
@@ -717,33 +737,38 @@ namespace pe
             double const* uc = arena + V.f_sptr[c];
             int const* rel = V.f_rel + V.f_rows_ptr[c];
             for(int i = t0; i < V.f_u[c]; i += T) t[rel[i]] += uc[i];
-            tm.sync();
+            tm.sync_lds();
         }
         tm.for_each_wave(
             [&](int w, int lane, int NLw)
             {
                 if(w != 0) return;  // wavefront 0 runs the dependent chain in registers, without workgroup barriers
-                tm.tri_lower_unit(t, Lb, p, p, lane);
+                tm.tri_lower_unit(t, Lb, ldb, p, small ? m : p, lane);
             });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
         if(u > 0)
         {
-            int const chunks = T / u > 0 ? (T / u < p ? T / u : p) : 1;
-            team_matvec_sub(tm, Lg + p, m, u, p, t, part, t0, T);
             double* us = arena + V.f_sptr[s];
-            for(int i = t0; i < u; i += T)
+            if(small)
+                for(int i = t0; i < u; i += T) us[i] = t[p + i];
+            else
             {
-                double acc = t[p + i];
-                for(int c = 0; c < chunks; ++c) acc -= part[c * u + i];
-                us[i] = acc;
+                int const chunks = T / u > 0 ? (T / u < p ? T / u : p) : 1;
+                team_matvec_sub(tm, Lg + p, m, u, p, t, part, t0, T);
+                for(int i = t0; i < u; i += T)
+                {
+                    double acc = t[p + i];
+                    for(int c = 0; c < chunks; ++c) acc -= part[c * u + i];
+                    us[i] = acc;
+                }
             }
         }
-        tm.sync();
+        tm.sync_lds();  // w / update-vector stores drain behind the next front's loads (its first sync() is a full fence)
     }
 
     template <class Team>
-    PE_DEV void front_backward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_p)
+    PE_DEV void front_backward(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap_m, int cap_stage)
     {
         int const s = tm.uniform(s_in);
         int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
@@ -754,8 +779,9 @@ namespace pe
         double const* Ug = fac + V.f_uptr[s];
         int const* rows = V.f_rows + V.f_rows_ptr[s];
         double* t = lds;                              // [m]
-        double* Ub = lds + cap_m;                     // staged U11 [p x p, ld p]
-        double* part = Ub + cap_p * cap_p;            // [T] partial sums of U12 * x_U
+        double* Ub = lds + cap_m;                     // staged U11 [p x p, ld p] (+ U12 [p x u, ld p] behind it when small)
+        double* part = Ub + cap_stage;                // [T] partial sums of U12 * x_U
+        bool const small = m <= 64 && m * p <= cap_stage;
         for(int j = t0; j < u; j += T) t[p + j] = w[rows[j]];
         for(int i = t0; i < p; i += T) t[i] = w[c0 + i];
         {
@@ -766,8 +792,9 @@ namespace pe
                 Ub[idx] = Lg[i + k * m];
             }
         }
+        if(small) stage_copy<4>(Ub + p * p, Ug, p * u, t0, T);
         tm.sync();
-        if(u > 0)
+        if(u > 0 && !small)
         {
             int const chunks = T / p > 0 ? (T / p < u ? T / p : u) : 1;
             team_matvec_sub(tm, Ug, p, p, u, t + p, part, t0, T);
@@ -783,7 +810,7 @@ namespace pe
             [&](int w, int lane, int NLw)
             {
                 if(w != 0) return;
-                tm.tri_upper(t, Ub, p, p, lane);
+                tm.tri_upper(t, Ub, p, p, small ? u : 0, lane);
             });
         tm.sync();
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
@@ -800,17 +827,17 @@ namespace pe
                 auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
                 int const q1 = tm.uniform(wp[wv + 1]);
-                for(int q = tm.uniform(wp[wv]); q < q1; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+                for(int q = tm.uniform(wp[wv]); q < q1; ++q) front_forward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.lds_wave_stage);
             });
         tm.sync();
-        for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
+        for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q) front_forward(tm, V, b, V.coop_list[q], lds, V.max_m, V.lds_coop_stage);
     }
 
     template <class Team>
     PE_DEV void backward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
-        for(int q = V.coop_ptr[part + 1] - 1; q >= V.coop_ptr[part]; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.max_p);
+        for(int q = V.coop_ptr[part + 1] - 1; q >= V.coop_ptr[part]; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.lds_coop_stage);
         tm.sync();
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
@@ -818,7 +845,7 @@ namespace pe
                 auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
                 int const q0 = tm.uniform(wp[wv]);
-                for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.wave_p);
+                for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.lds_wave_stage);
             });
         tm.sync();
     }

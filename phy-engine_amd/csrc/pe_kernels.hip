@@ -23,6 +23,13 @@ namespace pe
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __device__ __forceinline__ int lanes() const { return 64; }
+        // LDS-only variant of wave_fence(): does not wait for outstanding global stores / loads (s_waitcnt lgkmcnt only)
+        __device__ __forceinline__ void wave_fence_lds() const
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
         // a value that is the same in every lane of the wavefront but that the compiler cannot prove uniform (anything
         // derived from the wavefront's index): moved to an SGPR so that the loads it indexes become scalar loads and
         // the address arithmetic leaves the vector ALU
@@ -62,12 +69,14 @@ namespace pe
         }
         // Triangular solves of the triangular-solve phase, p <= 64, one wavefront: lane i owns t[i]; the dependent chain
         // runs on lane broadcasts, the matrix columns (LDS, independent of the chain) are fetched four steps ahead.
-        // L y = t, unit lower triangle of Lb (ld)
-        __device__ __forceinline__ void tri_lower_unit(double* t, double const* Lb, int ld, int p, int lane) const
+        // L y = t: unit lower triangle of the first p columns of Lb (ld); rows p..nrows-1 (nrows <= 64) are the
+        // sub-diagonal block, updated by the same sweep (t[p..] -= L21 y)
+        __device__ __forceinline__ void tri_lower_unit(double* t, double const* Lb, int ld, int p, int nrows, int lane) const
         {
-            bool const own = lane < p;
+            bool const own = lane < nrows;
             double ti = own ? t[lane] : 0.0;
-            for(int k0 = 0; k0 + 1 < p; k0 += 4)
+            int const last = nrows > p ? p : p - 1;  // pivot steps that still have rows below them
+            for(int k0 = 0; k0 < last; k0 += 4)
             {
                 double l[4];
 #pragma unroll
@@ -82,11 +91,26 @@ namespace pe
             }
             if(own) t[lane] = ti;
         }
-        // U x = t, upper triangle of Ub (ld) with its diagonal
-        __device__ __forceinline__ void tri_upper(double* t, double const* Ub, int ld, int p, int lane) const
+        // U x = t: upper triangle of Ub (p x p, ld) with its diagonal.  nu > 0: first t[0..p) -= U12 * t[p..p+nu) with
+        // U12 (p x nu, ld p) stored right behind the p x p block (small fronts: everything on this wavefront).
+        __device__ __forceinline__ void tri_upper(double* t, double const* Ub, int ld, int p, int nu, int lane) const
         {
             bool const own = lane < p;
             double ti = own ? t[lane] : 0.0;
+            if(nu > 0)
+            {
+                double const* U12 = Ub + p * ld;
+                double a0 = 0.0, a1 = 0.0;
+                int j = 0;
+                for(; j + 1 < nu; j += 2)
+                {
+                    double const u0 = own ? U12[lane + j * p] : 0.0, u1 = own ? U12[lane + (j + 1) * p] : 0.0;
+                    a0 += u0 * t[p + j];
+                    a1 += u1 * t[p + j + 1];
+                }
+                if(j < nu) a0 += (own ? U12[lane + j * p] : 0.0) * t[p + j];
+                ti -= a0 + a1;
+            }
             double const d = own ? Ub[lane + lane * ld] : 1.0;
             double const r = 1.0 / d;  // off the chain; the quotient below is refined to the correctly rounded t / d
             for(int k0 = p - 1; k0 >= 0; k0 -= 4)
@@ -179,6 +203,7 @@ namespace pe
         __device__ __forceinline__ int tid() const { return lane_; }
         __device__ __forceinline__ int size() const { return 64; }
         __device__ __forceinline__ void sync() const { wave_fence(); }
+        __device__ __forceinline__ void sync_lds() const { wave_fence_lds(); }
         __device__ __forceinline__ int sync_or(int v) const { return __any(v); }
         __device__ __forceinline__ int n_waves() const { return 1; }
         template <class F>
@@ -195,6 +220,14 @@ namespace pe
         __device__ __forceinline__ int tid() const { return static_cast<int>(threadIdx.x); }
         __device__ __forceinline__ int size() const { return static_cast<int>(blockDim.x); }
         __device__ __forceinline__ void sync() const { __syncthreads(); }
+        // barrier that orders LDS traffic only: global stores stay in flight across it (whoever reads them later does
+        // so behind a full sync())
+        __device__ __forceinline__ void sync_lds() const
+        {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
         __device__ __forceinline__ int sync_or(int v) const { return __syncthreads_or(v); }
         __device__ __forceinline__ int n_waves() const { return static_cast<int>(blockDim.x) >> 6; }
         template <class F>
@@ -334,9 +367,9 @@ namespace pe
         if(!V.active[b]) return;
         HipTeam tm;
         int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.max_p);
+        if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
         else
-            front_forward(tm, V, b, s, pe_lds, V.max_m, V.max_p);
+            front_forward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
     }
 
     __global__ void __launch_bounds__(256) k_m2_finish(DevView V)

@@ -14,6 +14,7 @@ namespace pe
         SerialTeam wave_team(int) const { return SerialTeam{1}; }
         int tid() const { return 0; }
         int uniform(int v) const { return v; }
+        void sync_lds() const {}
         int size() const { return 1; }
         void sync() const {}
         int sync_or(int v) const { return v; }
@@ -41,13 +42,16 @@ namespace pe
             }
             return 0;
         }
-        void tri_lower_unit(double* t, double const* Lb, int ld, int p, int) const
+        void tri_lower_unit(double* t, double const* Lb, int ld, int p, int nrows, int) const
         {
-            for(int k = 0; k + 1 < p; ++k)
-                for(int i = k + 1; i < p; ++i) t[i] -= Lb[i + k * ld] * t[k];
+            for(int k = 0; k < p; ++k)
+                for(int i = k + 1; i < nrows; ++i) t[i] -= Lb[i + k * ld] * t[k];
         }
-        void tri_upper(double* t, double const* Ub, int ld, int p, int) const
+        void tri_upper(double* t, double const* Ub, int ld, int p, int nu, int) const
         {
+            double const* U12 = Ub + p * ld;
+            for(int j = 0; j < nu; ++j)
+                for(int i = 0; i < p; ++i) t[i] -= U12[i + j * p] * t[p + j];
             for(int k = p - 1; k >= 0; --k)
             {
                 t[k] = t[k] / Ub[k + k * ld];
@@ -136,9 +140,9 @@ namespace pe
             for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
             for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
             for(int l = 0; l < V.n_top_levels; ++l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.max_p);
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int l = V.n_top_levels - 1; l >= 0; --l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.max_p);
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
             for(int k = 0; k < V.rows; ++k)
             {

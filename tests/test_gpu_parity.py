@@ -229,3 +229,18 @@ def test_multi_workgroup_batch_matches_single_workgroup(monkeypatch):
         e.close()
     assert np.array_equal(out[0][1], out[1][1])
     assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-9 * np.max(np.abs(out[0][0]))
+
+
+def test_reuse_factor_multi_workgroup():
+    """Same as test_reuse_factor_option_gives_same_answer on M10k (batch 1 => the multi-workgroup schedule)."""
+    deck = pe.deck.rc_mesh(100, 100, 3, False)
+    out = []
+    e = pe.ffi.Engine(device=0)
+    for refac in (1, 0):
+        e.set_options(g_min=0.0, refactor_every_solve=refac)
+        e.load_deck(deck)
+        e.reset()
+        e.analyze_tr(1e-10, 12)
+        out.append(e.solution()[0])
+    e.close()
+    assert np.max(np.abs(out[0] - out[1])) <= 1e-13
