@@ -48,13 +48,30 @@ enum pe_hip_kind
     PE_HIP_VDC = 4,  /* nodes a,b +branch params: V                          (linear/VDC.h:82-97) */
     PE_HIP_VAC = 5,  /* nodes a,b +branch params: Vp, omega[rad/s], phase[rad] (linear/VAC.h:162-179) */
     PE_HIP_IDC = 6,  /* nodes a,b        params: I                           (linear/IDC.h:84-95) */
-    PE_HIP_DIODE = 7 /* nodes a,c        params: Is,N,Isr,Nr,Temp,Ibv,Bv,Bv_set,Area,tt, tt_in_tr
+    PE_HIP_DIODE = 7,/* nodes a,c        params: Is,N,Isr,Nr,Temp,Ibv,Bv,Bv_set,Area,tt, tt_in_tr
                                                                             (non-linear/PN_junction.h:296-503;
                                                                              tt_in_tr=0 for the diodes of a
                                                                              full_bridge_rectifier, which has no
                                                                              iterate_tr: base.h:248-264) */
+    /* ---- the remaining linear stampers.  Four-pin kinds take nodes [count][4], kinds with two
+     * branches take branch [count][2]; pins in the reference's pin order. */
+    PE_HIP_IAC = 8,    /* nodes a,b           params: Ip, omega[rad/s], phase[rad]  TR/TROP only, nothing in OP/DC (linear/IAC.h:124-160) */
+    PE_HIP_VCCS = 9,   /* nodes S,T,P,Q       params: g       I(S->T) = g (vP - vQ)                         (linear/VCCS.h:80-95) */
+    PE_HIP_VCVS = 10,  /* nodes S,T,P,Q +1 br params: mu      vS - vT = mu (vP - vQ)                        (linear/VCVS.h:81-102) */
+    PE_HIP_CCCS = 11,  /* nodes S,T,P,Q +1 br params: alpha   sense branch P->Q (a short), I(S->T) = alpha i (linear/CCCS.h:81-100) */
+    PE_HIP_CCVS = 12,  /* nodes S,T,P,Q +2 br params: r       branches: output k, sense c; vS - vT = r i_c  (linear/CCVS.h:80-106) */
+    PE_HIP_OPAMP = 13, /* nodes S,T,P,Q +1 br params: mu      output P,Q driven by mu (vS - vT)             (linear/op_amp.h:64-83) */
+    PE_HIP_XFMR = 14,  /* nodes P,Q,S,T +2 br params: n       ideal transformer Vp = n Vs, Is = -n Ip       (linear/transformer.h:67-98) */
+    PE_HIP_SWITCH = 15,/* nodes a,b     +1 br params: cut_through (0/1): D = -(cut ? 0 : r_open)            (controller/switch.h:86-103) */
+    PE_HIP_VGEN = 16,  /* nodes +,-     +1 br params: type, Vh, Vl, freq[Hz], duty, phase[rad], tr, tf
+                                              type 0 sawtooth, 1 square, 2 pulse, 3 triangle; OP/DC/TROP take t = 0
+                                              (generator/sawtooth.h:88-107, square.h:93-110, pulse.h:107-141, triangle.h:88-112) */
+    PE_HIP_COUPLED_L = 17 /* nodes p1,p2,s1,s2 +2 br params: L1, L2, k  trapezoidal 2x2 Thevenin companion in TR, two
+                                              shorts otherwise (linear/coupled_inductors.h:92-115,160-246) */
 };
 #define PE_HIP_DIODE_NPARAM 11
+#define PE_HIP_VGEN_NPARAM 8
+#define PE_HIP_KIND_MAX 17
 
 /* analysis modes (phy_engine::analyze_type, circuits/analyze.h:7-16) */
 enum pe_hip_mode
@@ -69,8 +86,8 @@ typedef struct pe_hip_device_table
 {
     int kind;             /* pe_hip_kind */
     int count;            /* devices in this table */
-    const int* nodes;     /* [count][2] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin */
-    const int* branch;    /* [count] global branch index (0-based, after digital drives) for L/VDC/VAC, else NULL */
+    const int* nodes;     /* [count][pins] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin (pins = 2, or 4: see pe_hip_kind) */
+    const int* branch;    /* [count][branches] global branch index (0-based, after digital drives) for kinds with branch rows, else NULL */
     const double* params; /* [batch][count][ncol] when params_batched, else [count][ncol] (shared by every instance) */
     int params_batched;
 } pe_hip_device_table;
@@ -83,6 +100,7 @@ typedef struct pe_hip_options
     double g_min;
     int max_newton; /* 0 -> 64 */
     int refactor_every_solve; /* 1 (default): factor on every solve_once like the reference; 0: reuse the factors of a linear circuit while dt is unchanged */
+    double r_open; /* contact resistance of an open switch (environment.h r_open; <= 0 -> 1e12, circuit.h:1012) */
 } pe_hip_options;
 
 /* mirrors cuda_sparse_lu::timings (cuda_sparse_lu.h:27-34) */

@@ -32,6 +32,19 @@
 #include <phy_engine/model/models/linear/VDC.h>
 #include <phy_engine/model/models/linear/VAC.h>
 #include <phy_engine/model/models/linear/IDC.h>
+#include <phy_engine/model/models/linear/IAC.h>
+#include <phy_engine/model/models/linear/VCCS.h>
+#include <phy_engine/model/models/linear/VCVS.h>
+#include <phy_engine/model/models/linear/CCCS.h>
+#include <phy_engine/model/models/linear/CCVS.h>
+#include <phy_engine/model/models/linear/op_amp.h>
+#include <phy_engine/model/models/linear/transformer.h>
+#include <phy_engine/model/models/linear/coupled_inductors.h>
+#include <phy_engine/model/models/controller/switch.h>
+#include <phy_engine/model/models/generator/sawtooth.h>
+#include <phy_engine/model/models/generator/square.h>
+#include <phy_engine/model/models/generator/pulse.h>
+#include <phy_engine/model/models/generator/triangle.h>
 #include <phy_engine/model/models/non-linear/PN_junction.h>
 #include <phy_engine/model/models/non-linear/full_bridge_rectifier.h>
 #include <phy_engine/netlist/impl.h>
@@ -53,7 +66,7 @@ struct deck
 
 static int n_pins_of(std::string const& k)
 {
-    if(k == "FBR") return 4;
+    if(k == "FBR" || k == "VCCS" || k == "VCVS" || k == "CCCS" || k == "CCVS" || k == "OPAMP" || k == "XFMR" || k == "KL") return 4;
     return 2;
 }
 
@@ -121,6 +134,21 @@ static bool build(pe::circult& c, deck const& d)
             m = add_model(nl, std::move(pn)).mod;
         }
         else if(l.kind == "FBR") m = add_model(nl, pe::model::full_bridge_rectifier{}).mod;
+        else if(l.kind == "IAC") m = add_model(nl, pe::model::IAC{.m_Ip = P(0, 1.0), .m_omega = P(1, 50.0), .m_phase = P(2, 0.0)}).mod;
+        else if(l.kind == "VCCS") m = add_model(nl, pe::model::VCCS{.m_g = P(0, 1.0)}).mod;
+        else if(l.kind == "VCVS") m = add_model(nl, pe::model::VCVS{.m_mu = P(0, 1.0)}).mod;
+        else if(l.kind == "CCCS") m = add_model(nl, pe::model::CCCS{.m_alpha = P(0, 1.0)}).mod;
+        else if(l.kind == "CCVS") m = add_model(nl, pe::model::CCVS{.m_r = P(0, 1.0)}).mod;
+        else if(l.kind == "OPAMP") m = add_model(nl, pe::model::op_amp{.mu = P(0, 1e5)}).mod;
+        else if(l.kind == "XFMR") m = add_model(nl, pe::model::transformer{.n = P(0, 1.0)}).mod;
+        else if(l.kind == "SW") m = add_model(nl, pe::model::single_pole_switch{.cut_through = P(0, 0.0) != 0.0}).mod;
+        else if(l.kind == "SAW") m = add_model(nl, pe::model::sawtooth_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .phase = P(3, 0.0)}).mod;
+        else if(l.kind == "SQR")
+            m = add_model(nl, pe::model::square_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .duty = P(3, 0.5), .phase = P(4, 0.0)}).mod;
+        else if(l.kind == "PULSE")
+            m = add_model(nl, pe::model::pulse_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .duty = P(3, 0.5), .phase = P(4, 0.0), .tr = P(5, 0.0), .tf = P(6, 0.0)}).mod;
+        else if(l.kind == "TRI") m = add_model(nl, pe::model::triangle_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .phase = P(3, 0.0)}).mod;
+        else if(l.kind == "KL") m = add_model(nl, pe::model::coupled_inductors{.L1 = P(0, 1e-3), .L2 = P(1, 1e-3), .k = P(2, 0.99)}).mod;
         else
         {
             std::fprintf(stderr, "ref_driver: unknown device kind %s\n", l.kind.c_str());
@@ -189,7 +217,7 @@ static std::vector<double> snapshot(pe::circult const& c)
 static void usage()
 {
     std::fprintf(stderr,
-                 "usage: ref_driver <deck> --analysis TR|DC|OP|TROP [--dt X --steps K] [--gmin G]\n"
+                 "usage: ref_driver <deck> --analysis TR|DC|OP|TROP [--dt X --steps K] [--gmin G] [--ropen R]\n"
                  "                  [--snap s1,s2,..|all] [--out prefix] [--dump-mna] [--check-analyze]\n"
                  "       ref_driver <deck> --bench --dt X --steps K [--warmup W] [--gmin G]\n");
 }
@@ -203,7 +231,7 @@ int main(int argc, char** argv)
     }
     char const* deck_path = argv[1];
     std::string analysis = "TR", out = "ref_out", snaps;
-    double dt = 0.0, gmin = 0.0;
+    double dt = 0.0, gmin = 0.0, ropen = 0.0;
     long steps = 0, warmup = 1;
     bool bench = false, dump_mna = false, check_analyze = false;
     for(int i = 2; i < argc; ++i)
@@ -215,6 +243,7 @@ int main(int argc, char** argv)
         else if(a == "--steps") steps = std::strtol(next(), nullptr, 10);
         else if(a == "--warmup") warmup = std::strtol(next(), nullptr, 10);
         else if(a == "--gmin") gmin = std::strtod(next(), nullptr);
+        else if(a == "--ropen") ropen = std::strtod(next(), nullptr);
         else if(a == "--snap") snaps = next();
         else if(a == "--out") out = next();
         else if(a == "--bench") bench = true;
@@ -242,6 +271,7 @@ int main(int argc, char** argv)
     pe::circult c{};
     c.set_analyze_type(at);
     c.env.g_min = gmin;
+    if(ropen > 0.0) c.env.r_open = ropen;
     if(!build(c, d)) return 2;
 
     using clk = std::chrono::steady_clock;
@@ -357,6 +387,7 @@ int main(int argc, char** argv)
         pe::circult c2{};
         c2.set_analyze_type(at);
         c2.env.g_min = gmin;
+        if(ropen > 0.0) c2.env.r_open = ropen;
         build(c2, d);
         // run analyze() one step at a time (t_stop = dt) so FP accumulation of the loop bound cannot change the count
         bool ok = true;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <utility>
 
 namespace pe
 {
@@ -17,6 +18,65 @@ namespace pe
 
         inline int row_of(int node_id) { return node_id == 0 ? -1 : node_id - 1; }
     }  // namespace
+
+    int gen_pins(int kind) { return (kind == PE_HIP_IAC || kind == PE_HIP_SWITCH || kind == PE_HIP_VGEN) ? 2 : 4; }
+    int gen_branches(int kind)
+    {
+        switch(kind)
+        {
+            case PE_HIP_IAC:
+            case PE_HIP_VCCS: return 0;
+            case PE_HIP_CCVS:
+            case PE_HIP_XFMR:
+            case PE_HIP_COUPLED_L: return 2;
+            default: return 1;
+        }
+    }
+    int gen_ncol(int kind)
+    {
+        switch(kind)
+        {
+            case PE_HIP_IAC:
+            case PE_HIP_COUPLED_L: return 3;
+            case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
+            default: return 1;
+        }
+    }
+    int gen_ndv(int kind) { return kind == PE_HIP_COUPLED_L ? 5 : 1; }
+    bool gen_static_value(int kind, double const* raw, double r_open, double& out)
+    {
+        switch(kind)
+        {
+            case PE_HIP_VCCS:
+            case PE_HIP_VCVS:
+            case PE_HIP_CCCS:
+            case PE_HIP_CCVS:
+            case PE_HIP_OPAMP:
+            case PE_HIP_XFMR: out = raw[0]; return true;
+            case PE_HIP_SWITCH: out = raw[0] != 0.0 ? 0.0 : r_open; return true;  // switch.h:93
+            default: return false;
+        }
+    }
+    void gen_derive(HostCircuit& hc, int g, int b)
+    {
+        auto const& d = hc.gen[g];
+        double const* raw = &hc.gen_par[static_cast<size_t>(b) * hc.gen_par_len + d.par];
+        if(d.kind == PE_HIP_IAC)
+        {
+            double* o = &hc.ts_par[(static_cast<size_t>(b) * hc.nTs() + d.aux) * 8];
+            for(int c = 0; c < 8; ++c) o[c] = c < 3 ? raw[c] : 0.0;
+        }
+        else if(d.kind == PE_HIP_VGEN)
+        {
+            double* o = &hc.ts_par[(static_cast<size_t>(b) * hc.nTs() + d.aux) * 8];
+            for(int c = 0; c < 8; ++c) o[c] = raw[c];
+        }
+        else if(d.kind == PE_HIP_COUPLED_L)
+        {
+            double* o = &hc.cl_par[(static_cast<size_t>(b) * hc.nCl() + d.aux) * 3];
+            for(int c = 0; c < 3; ++c) o[c] = raw[c];
+        }
+    }
 
     void diode_derive(double const* raw, double* der)
     {
@@ -73,6 +133,8 @@ namespace pe
         }
 
         // ---- pass 1: compact device arrays (devices with an unconnected pin stamp nothing: `if(node_0 && node_1)`)
+        hc.map_gen.assign(PE_HIP_KIND_MAX + 1, {});
+        std::vector<std::pair<int, int>> gen_src;  // (table, index in table) of every kept generic device
         std::vector<char> branch_used(n_branches, 0);
         for(int k = 0; k < n_drives; ++k) branch_used[k] = 1;
         for(int ti = 0; ti < n_tables; ++ti)
@@ -82,6 +144,63 @@ namespace pe
             {
                 hc.error = "device table with null arrays";
                 return false;
+            }
+            if(t.kind >= PE_HIP_IAC && t.kind <= PE_HIP_KIND_MAX)
+            {
+                int const pins = gen_pins(t.kind), nbr = gen_branches(t.kind), nc = gen_ncol(t.kind);
+                if(nbr > 0 && t.count > 0 && !t.branch)
+                {
+                    hc.error = "branch indices missing for a branch device table";
+                    return false;
+                }
+                auto& map = hc.map_gen[t.kind];
+                if(!map.empty())
+                {
+                    hc.error = "each device kind may appear in one table only";
+                    return false;
+                }
+                for(int i = 0; i < t.count; ++i)
+                {
+                    bool connected = true;
+                    HostCircuit::GenDev d{};
+                    d.kind = t.kind;
+                    d.aux = -1;
+                    for(int q = 0; q < 4; ++q) d.n[q] = -1;
+                    for(int q = 0; q < pins; ++q)
+                    {
+                        int const id = t.nodes[pins * i + q];
+                        if(id > n_nodes)
+                        {
+                            hc.error = "node id out of range";
+                            return false;
+                        }
+                        if(id < 0) connected = false;
+                        else
+                            d.n[q] = row_of(id);
+                    }
+                    for(int q = 0; q < nbr; ++q)
+                    {
+                        int const k = t.branch[nbr * i + q];
+                        if(k < n_drives || k >= n_branches || branch_used[k])
+                        {
+                            hc.error = "branch index out of range or used twice";
+                            return false;
+                        }
+                        branch_used[k] = 1;
+                        d.k[q] = N + k;
+                    }
+                    if(!connected)
+                    {
+                        map.push_back(-1);
+                        continue;
+                    }
+                    d.par = hc.gen_par_len;
+                    hc.gen_par_len += nc;
+                    map.push_back(static_cast<int>(hc.gen.size()));
+                    hc.gen.push_back(d);
+                    gen_src.push_back({ti, i});
+                }
+                continue;
             }
             int ncol = 1;
             if(t.kind == PE_HIP_VAC) ncol = 3;
@@ -209,6 +328,47 @@ namespace pe
             }
         }
         hc.nonlinear = hc.nD() > 0;
+        // generic devices: raw parameters per instance, auxiliary device arrays
+        hc.gen_par.assign(static_cast<size_t>(batch) * hc.gen_par_len, 0.0);
+        for(size_t g = 0; g < hc.gen.size(); ++g)
+        {
+            auto& d = hc.gen[g];
+            auto const& t = tables[gen_src[g].first];
+            int const i = gen_src[g].second, nc = gen_ncol(d.kind);
+            for(int inst = 0; inst < batch; ++inst)
+                for(int c = 0; c < nc; ++c)
+                    hc.gen_par[static_cast<size_t>(inst) * hc.gen_par_len + d.par + c] =
+                        t.params[((t.params_batched ? static_cast<size_t>(inst) * t.count : 0) + static_cast<size_t>(i)) * nc + c];
+            if(d.kind == PE_HIP_IAC || d.kind == PE_HIP_VGEN)
+            {
+                d.aux = hc.nTs();
+                int type = 0;
+                if(d.kind == PE_HIP_VGEN)
+                {
+                    double const ty = hc.gen_par[d.par];
+                    if(!(ty == 0.0 || ty == 1.0 || ty == 2.0 || ty == 3.0))
+                    {
+                        hc.error = "generator type must be 0 (sawtooth), 1 (square), 2 (pulse) or 3 (triangle)";
+                        return false;
+                    }
+                    type = 1 + static_cast<int>(ty);
+                }
+                hc.ts_kind.push_back(type);
+                hc.ts_dv.push_back(0);
+            }
+            else if(d.kind == PE_HIP_COUPLED_L)
+            {
+                d.aux = hc.nCl();
+                for(int q = 0; q < 4; ++q) hc.cl_n.push_back(d.n[q]);
+                hc.cl_k.push_back(d.k[0]);
+                hc.cl_k.push_back(d.k[1]);
+                hc.cl_dv.push_back(0);
+            }
+        }
+        hc.ts_par.assign(static_cast<size_t>(batch) * hc.nTs() * 8, 0.0);
+        hc.cl_par.assign(static_cast<size_t>(batch) * hc.nCl() * 3, 0.0);
+        for(size_t g = 0; g < hc.gen.size(); ++g)
+            for(int inst = 0; inst < batch; ++inst) gen_derive(hc, static_cast<int>(g), inst);
 
         // ---- dv layout
         int o = DV_FIXED;
@@ -223,6 +383,15 @@ namespace pe
         hc.dv_dg = o; o += hc.nD();
         hc.dv_di = o; o += hc.nD();
         hc.dv_drv = o; o += n_drives;
+        hc.dv_gen = o;
+        for(auto& d: hc.gen)
+        {
+            d.dv = o;
+            o += gen_ndv(d.kind);
+            if(d.kind == PE_HIP_IAC || d.kind == PE_HIP_VGEN) hc.ts_dv[d.aux] = d.dv;
+            else if(d.kind == PE_HIP_COUPLED_L)
+                hc.cl_dv[d.aux] = d.dv;
+        }
         hc.dv_len = o;
 
         // ---- pass 2: emit stamps in the reference's order: digital drives, models, g_min
@@ -297,6 +466,94 @@ namespace pe
             B_add(hc.d_a[i], hc.dv_di + i, true);
             B_add(hc.d_c[i], hc.dv_di + i, false);
         }
+        for(auto const& d: hc.gen)
+        {
+            int const *n = d.n, *k = d.k, v = d.dv;
+            switch(d.kind)
+            {
+                case PE_HIP_IAC:  // IAC.h:156-157
+                    B_add(n[0], v, true);
+                    B_add(n[1], v, false);
+                    break;
+                case PE_HIP_VCCS:  // VCCS.h:89-92
+                    A_add(n[0], n[2], v, false);
+                    A_add(n[0], n[3], v, true);
+                    A_add(n[1], n[2], v, true);
+                    A_add(n[1], n[3], v, false);
+                    break;
+                case PE_HIP_VCVS:  // VCVS.h:92-98
+                    A_set(n[0], k[0], DV_ONE, false);
+                    A_set(n[1], k[0], DV_ONE, true);
+                    A_set(k[0], n[0], DV_ONE, false);
+                    A_set(k[0], n[1], DV_ONE, true);
+                    A_set(k[0], n[2], v, true);
+                    A_set(k[0], n[3], v, false);
+                    break;
+                case PE_HIP_CCCS:  // CCCS.h:90-95
+                    A_set(n[0], k[0], v, false);
+                    A_set(n[1], k[0], v, true);
+                    A_set(n[2], k[0], DV_ONE, false);
+                    A_set(n[3], k[0], DV_ONE, true);
+                    A_set(k[0], n[2], DV_ONE, false);
+                    A_set(k[0], n[3], DV_ONE, true);
+                    break;
+                case PE_HIP_CCVS:  // CCVS.h:92-100
+                    A_set(n[0], k[0], DV_ONE, false);
+                    A_set(n[1], k[0], DV_ONE, true);
+                    A_set(n[2], k[1], DV_ONE, false);
+                    A_set(n[3], k[1], DV_ONE, true);
+                    A_set(k[0], n[0], DV_ONE, false);
+                    A_set(k[0], n[1], DV_ONE, true);
+                    A_set(k[1], n[2], DV_ONE, false);
+                    A_set(k[1], n[3], DV_ONE, true);
+                    A_set(k[0], k[1], v, true);
+                    break;
+                case PE_HIP_OPAMP:  // op_amp.h:74-80
+                    A_set(n[2], k[0], DV_ONE, false);
+                    A_set(n[3], k[0], DV_ONE, true);
+                    A_set(k[0], n[2], DV_ONE, false);
+                    A_set(k[0], n[3], DV_ONE, true);
+                    A_add(k[0], n[0], v, true);
+                    A_add(k[0], n[1], v, false);
+                    break;
+                case PE_HIP_XFMR:  // transformer.h:80-96 (pins P,Q,S,T; branches kP,kS)
+                    A_set(n[0], k[0], DV_ONE, false);
+                    A_set(n[1], k[0], DV_ONE, true);
+                    A_set(k[0], n[0], DV_ONE, false);
+                    A_set(k[0], n[1], DV_ONE, true);
+                    A_set(n[2], k[1], DV_ONE, false);
+                    A_set(n[3], k[1], DV_ONE, true);
+                    A_add(k[0], n[2], v, true);
+                    A_add(k[0], n[3], v, false);
+                    A_set(k[1], k[1], DV_ONE, false);
+                    A_set(k[1], k[0], v, false);
+                    break;
+                case PE_HIP_SWITCH:  // switch.h:96-100
+                    incidence(n[0], n[1], k[0]);
+                    A_set(k[0], k[0], v, true);
+                    break;
+                case PE_HIP_VGEN:  // pulse.h:134-138 & co.
+                    incidence(n[0], n[1], k[0]);
+                    B_set(k[0], v, false);
+                    break;
+                case PE_HIP_COUPLED_L:  // coupled_inductors.h:223-243 (zeros in the D / E cells reproduce the DC stamp :104-112)
+                    A_set(n[0], k[0], DV_ONE, false);
+                    A_set(n[1], k[0], DV_ONE, true);
+                    A_set(n[2], k[1], DV_ONE, false);
+                    A_set(n[3], k[1], DV_ONE, true);
+                    A_set(k[0], n[0], DV_ONE, false);
+                    A_set(k[0], n[1], DV_ONE, true);
+                    A_set(k[1], n[2], DV_ONE, false);
+                    A_set(k[1], n[3], DV_ONE, true);
+                    A_set(k[0], k[0], v + 0, true);
+                    A_set(k[0], k[1], v + 1, true);
+                    A_set(k[1], k[0], v + 1, true);
+                    A_set(k[1], k[1], v + 2, true);
+                    B_set(k[0], v + 3, false);
+                    B_set(k[1], v + 4, false);
+                    break;
+            }
+        }
         for(int n = 0; n < N; ++n) A_add(n, n, DV_GMIN, false);  // circuit.h:1107-1110
 
         // ---- CSR pattern
@@ -345,7 +602,7 @@ namespace pe
         return true;
     }
 
-    void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, std::vector<double>& avals)
+    void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, double r_open, std::vector<double>& avals)
     {
         std::vector<double> dv(hc.dv_len, 0.0);
         dv[DV_ONE] = 1.0;
@@ -358,6 +615,19 @@ namespace pe
         {
             double const* p = &hc.d_par[static_cast<size_t>(i) * DP_NCOL];
             dv[hc.dv_dg + i] = p[DP_IS_EFF] / p[DP_UTE] + p[DP_ISR_EFF] / p[DP_UTER];
+        }
+        for(auto const& d: hc.gen)
+        {
+            double const* raw = &hc.gen_par[d.par];
+            double sv;
+            if(gen_static_value(d.kind, raw, r_open, sv)) dv[d.dv] = sv;
+            else if(d.kind == PE_HIP_COUPLED_L && dyn)
+            {
+                double const M = raw[2] * std::sqrt(raw[0] * raw[1]);
+                dv[d.dv + 0] = 2.0 * raw[0] / dt;
+                dv[d.dv + 1] = 2.0 * M / dt;
+                dv[d.dv + 2] = 2.0 * raw[1] / dt;
+            }
         }
         int const nnz = static_cast<int>(hc.ci.size());
         avals.assign(nnz, 0.0);

@@ -40,6 +40,28 @@ namespace pe
         bool nonlinear{};
         std::string error;
 
+        // ---- the remaining linear stampers (PE_HIP_IAC .. PE_HIP_COUPLED_L), kept in one generic list
+        struct GenDev
+        {
+            int kind;
+            int n[4];   // MNA rows of the pins (-1 = ground)
+            int k[2];   // absolute rows of its branches
+            int par;    // offset of its raw parameter columns inside one instance's block of gen_par
+            int dv;     // first dv slot (gen_ndv(kind) slots)
+            int aux;    // index in ts_* (IAC, VGEN) or cl_* (COUPLED_L), else -1
+        };
+        std::vector<GenDev> gen;
+        int gen_par_len{};             // doubles per instance
+        std::vector<double> gen_par;   // [batch][gen_par_len]
+        std::vector<std::vector<int>> map_gen;  // [kind] original table index -> index in gen (-1: unconnected pin)
+        int dv_gen{};
+        std::vector<int> ts_kind, ts_dv;
+        std::vector<double> ts_par;    // [batch][nTs][8]
+        std::vector<int> cl_n, cl_k, cl_dv;
+        std::vector<double> cl_par;    // [batch][nCl][3]
+        int nTs() const { return static_cast<int>(ts_kind.size()); }
+        int nCl() const { return static_cast<int>(cl_dv.size()); }
+
         int nR() const { return static_cast<int>(r_a.size()); }
         int nC() const { return static_cast<int>(c_a.size()); }
         int nL() const { return static_cast<int>(l_a.size()); }
@@ -53,10 +75,21 @@ namespace pe
     bool build_circuit(int n_nodes, int n_branches, int batch, int n_tables, pe_hip_device_table const* tables, int n_drives, int const* drv_node,
                        double const* drv_volt, HostCircuit& hc);
 
+    // generic kinds: pins, branch rows, raw parameter columns, dv slots
+    int gen_pins(int kind);
+    int gen_branches(int kind);
+    int gen_ncol(int kind);
+    int gen_ndv(int kind);
+    // value of the (single) static dv slot of a generic device from its raw parameters; false for kinds whose slots are
+    // computed on the device (IAC, VGEN, COUPLED_L)
+    bool gen_static_value(int kind, double const* raw, double r_open, double& out);
+    // (re)derives ts_par / cl_par of generic device g, instance b, from gen_par
+    void gen_derive(HostCircuit& hc, int g, int b);
+
     // PN_junction prepare_foundation (PN_junction.h:296-354) for one diode: raw[PE_HIP_DIODE_NPARAM] -> der[DP_NCOL]
     void diode_derive(double const* raw, double* der);
 
     // Representative |values| of the A slots of instance 0 for the row matching (TR: capacitors 2C/dt, inductors
     // 2L/dt; DC-like: open / short), diodes at their zero-bias conductance.
-    void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, std::vector<double>& avals);
+    void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, double r_open, std::vector<double>& avals);
 }  // namespace pe

@@ -35,6 +35,7 @@ namespace pe
         int nnzA, dv_len;
         int nR, nC, nL, nVdc, nVac, nIdc, nD, nDrv;
         int nonlinear;
+        int nTs, nCl;  // time sources (IAC, generators), coupled-inductor pairs
         // ---- dv block offsets
         int dv_r, dv_cg, dv_ci, dv_lr, dv_lu, dv_vdc, dv_vac, dv_idc, dv_dg, dv_di, dv_drv;
         // ---- topology (shared by all instances); rows are MNA row indices, -1 = ground
@@ -42,6 +43,9 @@ namespace pe
         int const *l_a, *l_b, *l_k;  // l_k = absolute row of the branch
         int const *vac_k;
         int const *d_a, *d_c;
+        int const *ts_kind, *ts_dv;   // time source i: 0 = IAC, 1.. = generator type + 1; dv slot of its value
+        int const *cl_n, *cl_k;       // coupled inductors i: rows of p1,p2,s1,s2 [.][4]; absolute rows of the two branches [.][2]
+        int const* cl_dv;             // first of its five dv slots: req11, req12, req22, Ueq1, Ueq2
         // ---- stamping: CSR of contributions per A slot / per RHS row; entry = (dv index << 1) | negate
         int const *a_ptr, *a_src;
         int const *b_ptr, *b_src;
@@ -50,6 +54,8 @@ namespace pe
         double const* l_ind;
         double const* vac_par;  // [.][nVac][3] Vp, omega, phase
         double const* d_par;    // [.][nD][DP_NCOL]
+        double const* ts_par;   // [.][nTs][8]  IAC: Ip, omega, phase; generator: type, Vh, Vl, freq, duty, phase, tr, tf
+        double const* cl_par;   // [.][nCl][3]  L1, L2, k
         // ---- per-instance state
         double *c_hist, *c_prevg;          // [.][nC]
         double *d_udlast, *d_geq, *d_hist, *d_prevg;  // [.][nD]

@@ -123,6 +123,8 @@ namespace
         return code;
     }
 
+    double r_open_of(pe_hip_engine const* h) { return h->opt.r_open > 0.0 ? h->opt.r_open : 1e12; }  // circuit.h:1012
+
     void apply_options(pe_hip_engine* h, pe::DevView& V)
     {
         auto const& o = h->opt;
@@ -260,7 +262,7 @@ namespace
         if(h->sym_class == cls) return PE_HIP_OK;
         auto const t0 = clk::now();
         std::vector<double> av;
-        pe::estimate_values(h->hc, tr, dt, h->opt.g_min, av);
+        pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
         pe::SymbolicOptions const so = symbolic_options(h, h->hc.batch, h->hc.rows);
         if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
         {
@@ -586,8 +588,23 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
 {
     if(!h || !o) return PE_HIP_ERR_ARG;
     bool const gmin_changed = o->g_min != h->opt.g_min;
+    double const r_open_before = r_open_of(h);
     h->opt = *o;
     apply_options(h, h->V);
+    if(h->loaded && r_open_of(h) != r_open_before)
+    {
+        HIPCHK(h, hipSetDevice(h->device));
+        std::vector<double> col(h->hc.batch);
+        for(auto const& g: h->hc.gen)
+            if(g.kind == PE_HIP_SWITCH)
+            {
+                for(int b = 0; b < h->hc.batch; ++b)
+                    (void)pe::gen_static_value(g.kind, &h->hc.gen_par[static_cast<size_t>(b) * h->hc.gen_par_len + g.par], r_open_of(h), col[b]);
+                HIPCHK(h, hipMemcpy2D(h->V.dv + g.dv, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double), h->hc.batch,
+                                      hipMemcpyHostToDevice));
+            }
+        h->fact_valid = false;
+    }
     if(h->loaded && gmin_changed)
     {
         HIPCHK(h, hipSetDevice(h->device));
@@ -647,6 +664,8 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     V.dv_len = hc.dv_len;
     V.nR = hc.nR(); V.nC = hc.nC(); V.nL = hc.nL(); V.nVdc = hc.nVdc(); V.nVac = hc.nVac(); V.nIdc = hc.nIdc(); V.nD = hc.nD();
     V.nDrv = hc.n_drives;
+    V.nTs = hc.nTs();
+    V.nCl = hc.nCl();
     V.nonlinear = hc.nonlinear ? 1 : 0;
     V.dv_r = hc.dv_r; V.dv_cg = hc.dv_cg; V.dv_ci = hc.dv_ci; V.dv_lr = hc.dv_lr; V.dv_lu = hc.dv_lu; V.dv_vdc = hc.dv_vdc;
     V.dv_vac = hc.dv_vac; V.dv_idc = hc.dv_idc; V.dv_dg = hc.dv_dg; V.dv_di = hc.dv_di; V.dv_drv = hc.dv_drv;
@@ -667,6 +686,13 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     HIPCHK(h, P.upload(V.l_ind, hc.l_ind));
     HIPCHK(h, P.upload(V.vac_par, hc.vac_par));
     HIPCHK(h, P.upload(V.d_par, hc.d_par));
+    HIPCHK(h, P.upload(V.ts_kind, hc.ts_kind));
+    HIPCHK(h, P.upload(V.ts_dv, hc.ts_dv));
+    HIPCHK(h, P.upload(V.ts_par, hc.ts_par));
+    HIPCHK(h, P.upload(V.cl_n, hc.cl_n));
+    HIPCHK(h, P.upload(V.cl_k, hc.cl_k));
+    HIPCHK(h, P.upload(V.cl_dv, hc.cl_dv));
+    HIPCHK(h, P.upload(V.cl_par, hc.cl_par));
     size_t const B = static_cast<size_t>(hc.batch);
     HIPCHK(h, P.alloc(V.c_hist, B * hc.nC()));
     HIPCHK(h, P.alloc(V.c_prevg, B * hc.nC()));
@@ -702,6 +728,11 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
             for(int i = 0; i < hc.nVdc(); ++i) d[hc.dv_vdc + i] = hc.vdc_v[b * hc.nVdc() + i];
             for(int i = 0; i < hc.nIdc(); ++i) d[hc.dv_idc + i] = hc.idc_i[b * hc.nIdc() + i];
             for(int k = 0; k < hc.n_drives; ++k) d[hc.dv_drv + k] = hc.drv_volt[k];
+            for(auto const& g: hc.gen)
+            {
+                double sv;
+                if(pe::gen_static_value(g.kind, &hc.gen_par[b * hc.gen_par_len + g.par], r_open_of(h), sv)) d[g.dv] = sv;
+            }
         }
         double* ddv{};
         HIPCHK(h, P.alloc(ddv, dv.size(), false));
@@ -935,7 +966,43 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
         case PE_HIP_VAC: map = &hc.map_vac; break;
         case PE_HIP_IDC: map = &hc.map_idc; break;
         case PE_HIP_DIODE: map = &hc.map_d; break;
-        default: return fail(h, PE_HIP_ERR_ARG, "update_param: unknown kind");
+        default:
+            if(kind >= PE_HIP_IAC && kind <= PE_HIP_KIND_MAX) break;
+            return fail(h, PE_HIP_ERR_ARG, "update_param: unknown kind");
+    }
+    if(!map)
+    {
+        auto const& gm = hc.map_gen[kind];
+        if(index >= static_cast<int>(gm.size())) return fail(h, PE_HIP_ERR_ARG, "update_param: index out of range");
+        if(column >= pe::gen_ncol(kind)) return PE_HIP_ERR_ARG;
+        int const g = gm[index];
+        if(g < 0) return PE_HIP_OK;
+        auto const& d = hc.gen[g];
+        if(kind == PE_HIP_VGEN && column == 0) return fail(h, PE_HIP_ERR_ARG, "update_param: the generator type is fixed at load time");
+        std::vector<double> col(B);
+        h->fact_valid = false;
+        for(int b = 0; b < B; ++b)
+        {
+            hc.gen_par[static_cast<size_t>(b) * hc.gen_par_len + d.par + column] = val(b);
+            pe::gen_derive(hc, g, b);
+        }
+        double sv;
+        if(pe::gen_static_value(kind, &hc.gen_par[d.par], r_open_of(h), sv))
+        {
+            for(int b = 0; b < B; ++b) (void)pe::gen_static_value(kind, &hc.gen_par[static_cast<size_t>(b) * hc.gen_par_len + d.par], r_open_of(h), col[b]);
+            HIPCHK(h, put_strided(h->V.dv + d.dv, hc.dv_len, col));
+        }
+        else if(kind == PE_HIP_COUPLED_L)
+        {
+            for(int b = 0; b < B; ++b) col[b] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.cl_par) + static_cast<size_t>(d.aux) * 3 + column, static_cast<size_t>(hc.nCl()) * 3, col));
+        }
+        else
+        {
+            for(int b = 0; b < B; ++b) col[b] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.ts_par) + static_cast<size_t>(d.aux) * 8 + column, static_cast<size_t>(hc.nTs()) * 8, col));
+        }
+        return PE_HIP_OK;
     }
     if(index >= static_cast<int>(map->size())) return fail(h, PE_HIP_ERR_ARG, "update_param: index out of range");
     int const j = (*map)[index];

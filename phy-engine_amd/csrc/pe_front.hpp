@@ -125,6 +125,34 @@ namespace pe
             }
         }
         {
+            // coupled_inductors.h:160-198: Req = (2/dt) [[L1 M],[M L2]], Ueq = -v_prev - Req i_prev
+            double const* par = V.cl_par + static_cast<long long>(b) * V.nCl * 3;
+            for(int i = tm.tid(); i < V.nCl; i += tm.size())
+            {
+                double r11 = 0.0, r12 = 0.0, r22 = 0.0, u1 = 0.0, u2 = 0.0;
+                if(dt > 0.0)
+                {
+                    double const L1 = par[3 * i], L2 = par[3 * i + 1], kc = par[3 * i + 2];
+                    double const M = kc * sqrt(L1 * L2);
+                    double const req_scale = 2.0 / dt;
+                    r11 = req_scale * L1;
+                    r12 = req_scale * M;
+                    r22 = req_scale * L2;
+                    double const v1 = volt(x, V.cl_n[4 * i]) - volt(x, V.cl_n[4 * i + 1]);
+                    double const v2 = volt(x, V.cl_n[4 * i + 2]) - volt(x, V.cl_n[4 * i + 3]);
+                    double const i1 = x[V.cl_k[2 * i]], i2 = x[V.cl_k[2 * i + 1]];
+                    u1 = -v1 - (r11 * i1 + r12 * i2);
+                    u2 = -v2 - (r12 * i1 + r22 * i2);
+                }
+                int const o = V.cl_dv[i];
+                dv[o] = r11;
+                dv[o + 1] = r12;
+                dv[o + 2] = r22;
+                dv[o + 3] = u1;
+                dv[o + 4] = u2;
+            }
+        }
+        {
             double* udl = V.d_udlast + static_cast<long long>(b) * V.nD;
             double* geq = V.d_geq + static_cast<long long>(b) * V.nD;
             double* hist = V.d_hist + static_cast<long long>(b) * V.nD;
@@ -175,6 +203,53 @@ namespace pe
             {
                 dv[V.dv_lr + i] = 0.0;
                 dv[V.dv_lu + i] = 0.0;
+            }
+            for(int i = tm.tid(); i < V.nCl; i += tm.size())
+                for(int q = 0; q < 5; ++q) dv[V.cl_dv[i] + q] = 0.0;
+        }
+        {
+            // time sources: TR at t, TROP / OP / DC at t = 0 (base.h:248-304 fallbacks; generators' iterate_dc = iterate_tr(0));
+            // IAC has an empty iterate_dc (IAC.h:124-128)
+            double const* par = V.ts_par + static_cast<long long>(b) * V.nTs * 8;
+            for(int i = tm.tid(); i < V.nTs; i += tm.size())
+            {
+                double const* p = par + 8 * i;
+                int const kind = V.ts_kind[i];
+                double const tt = tr ? t : 0.0;
+                double val = 0.0;
+                if(kind == 0)
+                {
+                    if(tr || mode == MODE_TROP) val = p[0] * sin(p[1] * tt + p[2]);
+                }
+                else
+                {
+                    double const Vh = p[1], Vl = p[2], freq = p[3], duty = p[4], phase = p[5], trise = p[6], tfall = p[7];
+                    double const T = 1.0 / freq;
+                    double const t0 = tt + phase / (2.0 * 3.14159265358979323846) / freq;
+                    double const tm_ = fmod(t0, T);
+                    if(kind == 1) val = Vl + ((Vh - Vl) / T) * tm_;                       // sawtooth.h:94-98
+                    else if(kind == 2)
+                        val = tm_ < duty * T ? Vh : Vl;                                  // square.h:99-101
+                    else if(kind == 3)                                                     // pulse.h:113-132
+                    {
+                        double const Ton = duty * T;
+                        if(tm_ < trise) val = Vl + ((Vh - Vl) / fmax(trise, 1e-30)) * tm_;
+                        else if(tm_ < Ton - tfall)
+                            val = Vh;
+                        else if(tm_ < Ton)
+                            val = Vh - ((Vh - Vl) / fmax(tfall, 1e-30)) * (tm_ - (Ton - tfall));
+                        else
+                            val = Vl;
+                    }
+                    else                                                                   // triangle.h:94-103
+                    {
+                        double const amp = Vh - Vl;
+                        if(tm_ < 0.5 * T) val = Vl + (2.0 * amp / T) * tm_;
+                        else
+                            val = Vh - (2.0 * amp / T) * (tm_ - 0.5 * T);
+                    }
+                }
+                dv[V.ts_dv[i]] = val;
             }
         }
         {

@@ -13,6 +13,19 @@ numbering exactly as the reference's `circult::prepare()` does, circuits/circuit
     IDC a b  I                      # model/models/linear/IDC.h
     D   a c  Is N Isr Nr Temp Ibv Bv Bv_set Area tt   # non-linear/PN_junction.h
     FBR a b p m                     # non-linear/full_bridge_rectifier.h (4 default diodes)
+    IAC  a b  Ip omega phase        # linear/IAC.h
+    VCCS s t p q  g                 # linear/VCCS.h
+    VCVS s t p q  mu                # linear/VCVS.h                         (1 branch)
+    CCCS s t p q  alpha             # linear/CCCS.h                         (1 branch)
+    CCVS s t p q  r                 # linear/CCVS.h                         (2 branches)
+    OPAMP s t p q  mu               # linear/op_amp.h                       (1 branch)
+    XFMR p q s t  n                 # linear/transformer.h                  (2 branches)
+    SW   a b  cut_through           # controller/switch.h                   (1 branch)
+    SAW  p m  Vh Vl freq phase      # generator/sawtooth.h                  (1 branch)
+    SQR  p m  Vh Vl freq duty phase # generator/square.h                    (1 branch)
+    PULSE p m Vh Vl freq duty phase tr tf   # generator/pulse.h             (1 branch)
+    TRI  p m  Vh Vl freq phase      # generator/triangle.h                  (1 branch)
+    KL   p1 p2 s1 s2  L1 L2 k       # linear/coupled_inductors.h            (2 branches)
 
 Node id -1 = unconnected pin.  Values are printed with %.17g so every consumer reads the same doubles.
 """
@@ -23,9 +36,12 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-KINDS = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "FBR")
-NPINS = {"R": 2, "C": 2, "L": 2, "VDC": 2, "VAC": 2, "IDC": 2, "D": 2, "FBR": 4}
-NBRANCH = {"R": 0, "C": 0, "L": 1, "VDC": 1, "VAC": 1, "IDC": 0, "D": 0, "FBR": 0}
+KINDS = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "FBR", "IAC", "VCCS", "VCVS", "CCCS", "CCVS", "OPAMP", "XFMR", "SW", "SAW", "SQR", "PULSE",
+         "TRI", "KL")
+NPINS = {"R": 2, "C": 2, "L": 2, "VDC": 2, "VAC": 2, "IDC": 2, "D": 2, "FBR": 4, "IAC": 2, "VCCS": 4, "VCVS": 4, "CCCS": 4, "CCVS": 4,
+         "OPAMP": 4, "XFMR": 4, "SW": 2, "SAW": 2, "SQR": 2, "PULSE": 2, "TRI": 2, "KL": 4}
+NBRANCH = {"R": 0, "C": 0, "L": 1, "VDC": 1, "VAC": 1, "IDC": 0, "D": 0, "FBR": 0, "IAC": 0, "VCCS": 0, "VCVS": 1, "CCCS": 1, "CCVS": 2,
+           "OPAMP": 1, "XFMR": 2, "SW": 1, "SAW": 1, "SQR": 1, "PULSE": 1, "TRI": 1, "KL": 2}
 # defaults follow the reference structs' member initialisers
 DEFAULTS = {
     "R": (10.0,),
@@ -37,7 +53,18 @@ DEFAULTS = {
     # Is N Isr Nr Temp Ibv Bv Bv_set Area tt   (PN_junction.h:26-37)
     "D": (1e-14, 1.0, 0.0, 2.0, 27.0, 1e-3, 40.0, 1.0, 1.0, 0.0),
     "FBR": (),
+    "IAC": (1.0, 50.0, 0.0),
+    "VCCS": (1.0,), "VCVS": (1.0,), "CCCS": (1.0,), "CCVS": (1.0,), "OPAMP": (1e5,), "XFMR": (1.0,),
+    "SW": (0.0,),
+    "SAW": (5.0, 0.0, 1e3, 0.0),
+    "SQR": (5.0, 0.0, 1e3, 0.5, 0.0),
+    "PULSE": (5.0, 0.0, 1e3, 0.5, 0.0, 0.0, 0.0),
+    "TRI": (5.0, 0.0, 1e3, 0.0),
+    "KL": (1e-3, 1e-3, 0.99),
 }
+# generators -> (type code of PE_HIP_VGEN, positions of Vh Vl freq duty phase tr tf in the deck's parameter tuple, -1 = absent)
+VGEN_LAYOUT = {"SAW": (0, (0, 1, 2, -1, 3, -1, -1)), "SQR": (1, (0, 1, 2, 3, 4, -1, -1)), "PULSE": (2, (0, 1, 2, 3, 4, 5, 6)),
+               "TRI": (3, (0, 1, 2, -1, 3, -1, -1))}
 
 
 @dataclass
@@ -304,4 +331,157 @@ def floating_rc() -> Deck:
     d.n_nodes = 2
     d.add("R", (1, 2), 1000.0)
     d.add("C", (1, 2), 1e-6)
+    return d
+
+
+# --------------------------------------------------------------------------------------------
+# decks of the reference's own model tests (test/0005.models/*.cpp) + transient variants
+# --------------------------------------------------------------------------------------------
+def vccs_dc() -> Deck:
+    """test/0005.models/vccs_dc.cpp: VDC 5 V control, VCCS 2 mS sinking into 1 kOhm: vout = -g vctrl rload = -10 V."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("VDC", (1, 0), 5.0)
+    d.add("VCCS", (2, 0, 1, 0), 2e-3)
+    d.add("R", (2, 0), 1000.0)
+    return d
+
+
+def vcvs_gain() -> Deck:
+    """test/0005.models/vcvs_gain.cpp: mu = 2, Vin = 1 V: vout = 2 V."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("VDC", (1, 0), 1.0)
+    d.add("VCVS", (2, 0, 1, 0), 2.0)
+    d.add("R", (2, 0), 1000.0)
+    return d
+
+
+def cccs_dc() -> Deck:
+    """test/0005.models/cccs_dc.cpp: i_ctrl = 5 mA, alpha = 3: vout = -15 V."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 5.0)
+    d.add("R", (1, 2), 1000.0)
+    d.add("CCCS", (3, 0, 2, 0), 3.0)
+    d.add("R", (3, 0), 1000.0)
+    return d
+
+
+def ccvs_dc() -> Deck:
+    """test/0005.models/ccvs_dc.cpp: i_ctrl = 5 mA, r = 2 kOhm: vout = 10 V."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 5.0)
+    d.add("R", (1, 2), 1000.0)
+    d.add("CCVS", (3, 0, 2, 0), 2000.0)
+    d.add("R", (3, 0), 1000.0)
+    return d
+
+
+def op_amp_follower() -> Deck:
+    """test/0005.models/op_amp_follower.cpp: mu = 1e6 follower: vout = mu/(1+mu) Vin."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("VDC", (1, 0), 1.0)
+    d.add("OPAMP", (1, 2, 2, 0), 1e6)
+    d.add("R", (2, 0), 1000.0)
+    return d
+
+
+def transformer_ratio() -> Deck:
+    """test/0005.models/transformer_ratio.cpp: n = 2, 4 V primary: 2 V on the 100 Ohm secondary load, Is + n Ip = 0."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("VDC", (1, 0), 4.0)
+    d.add("XFMR", (1, 0, 2, 0), 2.0)
+    d.add("R", (2, 0), 100.0)
+    return d
+
+
+def switch_divider(closed: bool = False) -> Deck:
+    """test/0005.models/switch_r_open.cpp (open) / switch.cpp (closed): VDC 1 V - switch - 1 kOhm."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("SW", (1, 2), 1.0 if closed else 0.0)
+    d.add("R", (2, 0), 1000.0)
+    d.add("VDC", (1, 0), 1.0)
+    return d
+
+
+def generator_dc() -> Deck:
+    """test/0005.models/generator_dc.cpp: eight generators, values at t = 0."""
+    d = Deck()
+    d.n_nodes = 8
+    Vh, Vl, f = 5.0, 1.0, 1000.0
+    d.add("SQR", (1, 0), Vh, Vl, f, 0.25, 0.0)
+    d.add("SQR", (2, 0), Vh, Vl, f, 0.25, math.pi)
+    d.add("SAW", (3, 0), Vh, Vl, f, 0.0)
+    d.add("SAW", (4, 0), Vh, Vl, f, math.pi)
+    d.add("TRI", (5, 0), Vh, Vl, f, 0.0)
+    d.add("TRI", (6, 0), Vh, Vl, f, math.pi)
+    d.add("PULSE", (7, 0), Vh, Vl, f, 0.1, 0.0, 0.0, 0.0)
+    d.add("PULSE", (8, 0), Vh, Vl, f, 0.1, 1.5 * math.pi, 0.0, 0.0)
+    for n in range(1, 9):   # a load on every source so that the branch currents are not all zero
+        d.add("R", (n, 0), 100.0 * n)
+    return d
+
+
+def generators_tr() -> Deck:
+    """Four generators (1 kHz .. 4 kHz, pulse with 20 us edges) each driving its own R-C low-pass; TR dt 5 us."""
+    d = Deck()
+    d.n_nodes = 8
+    d.add("SAW", (1, 0), 5.0, -1.0, 1e3, 0.3)
+    d.add("SQR", (2, 0), 3.0, 0.5, 2e3, 0.3, 1.0)
+    d.add("PULSE", (3, 0), 4.0, 0.0, 3e3, 0.5, 0.2, 2e-5, 3e-5)
+    d.add("TRI", (4, 0), 2.0, -2.0, 4e3, 2.0)
+    for n in range(1, 5):
+        d.add("R", (n, n + 4), 1000.0)
+        d.add("C", (n + 4, 0), 1e-7)
+    return d
+
+
+def iac_rc() -> Deck:
+    """IAC 1 mA / 1 kHz into R || C (TR); nothing in DC."""
+    d = Deck()
+    d.n_nodes = 1
+    d.add("IAC", (0, 1), 1e-3, 2.0 * math.pi * 1e3, 0.5)
+    d.add("R", (1, 0), 1000.0)
+    d.add("C", (1, 0), 1e-7)
+    return d
+
+
+def coupled_inductors_tr(k: float = 0.0) -> Deck:
+    """test/0005.models/coupled_inductors_TR.cpp (k = 0) and a coupled variant: VDC 1 V - L1 - 10 Ohm, L2 - 10 Ohm."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 1.0)
+    d.add("R", (2, 0), 10.0)
+    d.add("KL", (1, 2, 0, 3), 1e-3, 1e-3, k)
+    d.add("R", (3, 0), 10.0)
+    return d
+
+
+def controlled_mix() -> Deck:
+    """Every linear controlled source + transformer + closed/open switches + a diode in one transient deck."""
+    d = Deck()
+    d.n_nodes = 10
+    d.add("VAC", (1, 0), 2.0, 2.0 * math.pi * 1e4, 0.0)
+    d.add("R", (1, 2), 100.0)
+    d.add("C", (2, 0), 1e-7)
+    d.add("VCVS", (3, 0, 2, 0), 3.0)
+    d.add("R", (3, 4), 500.0)
+    d.add("D", (4, 0))
+    d.add("VCCS", (5, 0, 4, 0), 1e-3)
+    d.add("R", (5, 0), 2000.0)
+    d.add("C", (5, 0), 2e-8)
+    d.add("CCCS", (6, 0, 5, 7), 2.0)
+    d.add("R", (7, 0), 300.0)
+    d.add("R", (6, 0), 150.0)
+    d.add("XFMR", (6, 0, 8, 0), 0.5)
+    d.add("SW", (8, 9), 1.0)
+    d.add("R", (9, 0), 50.0)
+    d.add("SW", (9, 10), 0.0)
+    d.add("R", (10, 0), 1e4)
+    d.add("L", (8, 0), 1e-3)
     return d

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("PE_HIP_LIB", os.path.join(_HERE, "libpe_hip.so"))
 
 # pe_hip_kind
 R, CAP, L, VDC, VAC, IDC, DIODE = 1, 2, 3, 4, 5, 6, 7
+IAC, VCCS, VCVS, CCCS, CCVS, OPAMP, XFMR, SWITCH, VGEN, COUPLED_L = 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
 DIODE_NPARAM = 11
 MODE_OP, MODE_DC, MODE_TR, MODE_TROP = 0, 1, 4, 5
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
@@ -35,7 +36,7 @@ class DeviceTable(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("v_abstol", C.c_double), ("v_reltol", C.c_double), ("i_abstol", C.c_double), ("i_reltol", C.c_double),
-                ("g_min", C.c_double), ("max_newton", C.c_int), ("refactor_every_solve", C.c_int)]
+                ("g_min", C.c_double), ("max_newton", C.c_int), ("refactor_every_solve", C.c_int), ("r_open", C.c_double)]
 
 
 class Timings(C.Structure):
@@ -133,7 +134,9 @@ def deck_tables(deck, batch=1, overrides=None, n_drives=0):
     FBR devices expand to their four PN junctions (full_bridge_rectifier.h:19-50) with tt_in_tr = 0.
     """
     overrides = overrides or {}
-    groups = {k: {"nodes": [], "branch": [], "par": []} for k in ("R", "C", "L", "VDC", "VAC", "IDC", "D")}
+    from .deck import NBRANCH, VGEN_LAYOUT
+    names = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "IAC", "VCCS", "VCVS", "CCCS", "CCVS", "OPAMP", "XFMR", "SW", "VGEN", "KL")
+    groups = {k: {"nodes": [], "branch": [], "par": []} for k in names}
     k = n_drives
     for kind, nodes, par in deck.devices:
         if kind == "FBR":
@@ -143,18 +146,25 @@ def deck_tables(deck, batch=1, overrides=None, n_drives=0):
                 groups["D"]["nodes"].append((a, c))
                 groups["D"]["par"].append(dflt)
             continue
+        nb = NBRANCH[kind]
+        if kind in VGEN_LAYOUT:
+            ty, pos = VGEN_LAYOUT[kind]
+            dflt = (5.0, 0.0, 1e3, 0.5, 0.0, 0.0, 0.0)
+            par = (float(ty),) + tuple(par[q] if q >= 0 else dflt[j] for j, q in enumerate(pos))
+            kind = "VGEN"
         g = groups[kind]
         g["nodes"].append(nodes)
         g["par"].append(tuple(par) + ((1.0,) if kind == "D" else ()))
-        if kind in ("L", "VDC", "VAC"):
+        for _ in range(nb):
             g["branch"].append(k)
             k += 1
-    code = {"R": R, "C": CAP, "L": L, "VDC": VDC, "VAC": VAC, "IDC": IDC, "D": DIODE}
+    code = {"R": R, "C": CAP, "L": L, "VDC": VDC, "VAC": VAC, "IDC": IDC, "D": DIODE, "IAC": IAC, "VCCS": VCCS, "VCVS": VCVS, "CCCS": CCCS,
+            "CCVS": CCVS, "OPAMP": OPAMP, "XFMR": XFMR, "SW": SWITCH, "VGEN": VGEN, "KL": COUPLED_L}
     tables = []
     for name, g in groups.items():
         if not g["nodes"]:
             continue
-        nodes = np.ascontiguousarray(np.array(g["nodes"], dtype=np.int32).reshape(-1, 2))
+        nodes = np.ascontiguousarray(np.array(g["nodes"], dtype=np.int32))
         branch = np.ascontiguousarray(np.array(g["branch"], dtype=np.int32)) if g["branch"] else None
         if name in overrides:
             par = np.ascontiguousarray(overrides[name], dtype=np.float64)
@@ -215,8 +225,8 @@ class Engine:
             raise PeHipError(rc, lib().pe_hip_last_error(self._h).decode())
         return rc
 
-    def set_options(self, g_min=0.0, v_abstol=0.0, v_reltol=0.0, i_abstol=0.0, i_reltol=0.0, max_newton=0, refactor_every_solve=1):
-        o = Options(v_abstol, v_reltol, i_abstol, i_reltol, g_min, max_newton, refactor_every_solve)
+    def set_options(self, g_min=0.0, v_abstol=0.0, v_reltol=0.0, i_abstol=0.0, i_reltol=0.0, max_newton=0, refactor_every_solve=1, r_open=0.0):
+        o = Options(v_abstol, v_reltol, i_abstol, i_reltol, g_min, max_newton, refactor_every_solve, r_open)
         self._chk(lib().pe_hip_set_options(self._h, C.byref(o)))
 
     def set_digital_drives(self, nodes, volts):

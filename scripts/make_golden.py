@@ -50,6 +50,25 @@ for sd in range(2, 9):
 CASES["mesh100_lin_seed2"] = (("rc_mesh", {"W": 100, "H": 100, "seed": 2, "nonlinear": False}), "TR", 1e-10, 100, 0.0, "100", False)
 
 
+# the reference's own model tests (DC) + transient variants of the same devices
+for nm in ("vccs_dc", "vcvs_gain", "cccs_dc", "ccvs_dc", "op_amp_follower", "transformer_ratio", "generator_dc"):
+    CASES[nm] = ((nm, {}), "DC", 0.0, 0, 0.0, "", True)
+CASES["switch_open_dc"] = (("switch_divider", {"closed": False}), "DC", 0.0, 0, 0.0, "", True)
+CASES["switch_closed_dc"] = (("switch_divider", {"closed": True}), "DC", 0.0, 0, 0.0, "", True)
+CASES["switch_open_ropen1e6_dc"] = (("switch_divider", {"closed": False}), "DC", 0.0, 0, 0.0, "", True)
+R_OPEN = {"switch_open_ropen1e6_dc": 1e6}
+CASES["generators_tr"] = (("generators_tr", {}), "TR", 5e-6, 400, 0.0, "1,7,50,133,200,399,400", True)
+CASES["generators_trop"] = (("generators_tr", {}), "TROP", 5e-6, 20, 0.0, "0,1,20", True)
+CASES["iac_rc_tr"] = (("iac_rc", {}), "TR", 1e-5, 300, 0.0, "1,100,300", True)
+CASES["iac_rc_dc"] = (("iac_rc", {}), "DC", 0.0, 0, 0.0, "", True)
+CASES["iac_rc_trop"] = (("iac_rc", {}), "TROP", 1e-5, 10, 0.0, "0,1,10", True)
+CASES["coupled_l_k0_tr"] = (("coupled_inductors_tr", {"k": 0.0}), "TR", 1e-5, 10, 0.0, "1,10", True)
+CASES["coupled_l_k09_tr"] = (("coupled_inductors_tr", {"k": 0.9}), "TR", 1e-5, 100, 0.0, "1,10,100", True)
+CASES["coupled_l_k09_trop"] = (("coupled_inductors_tr", {"k": 0.9}), "TROP", 1e-5, 20, 0.0, "0,1,20", True)
+CASES["coupled_l_dc"] = (("coupled_inductors_tr", {"k": 0.5}), "DC", 0.0, 0, 0.0, "", True)
+CASES["controlled_mix_tr"] = (("controlled_mix", {}), "TR", 1e-6, 300, 0.0, "1,10,100,300", True)
+
+
 def tt_diode_deck():
     """test/0004.solver/pn_junction_tt_tr.cpp: VDC 0.7 + VAC 0.1 (omega*dt = pi/2) across a tt=1e-9 diode."""
     import math
@@ -75,11 +94,15 @@ def run_case(name):
         cmd = [DRIVER, dp, "--analysis", analysis, "--gmin", repr(gmin), "--out", out]
         if analysis in ("TR", "TROP"):
             cmd += ["--dt", repr(dt), "--steps", str(steps), "--snap", snaps]
+        if name in R_OPEN:
+            cmd += ["--ropen", repr(R_OPEN[name])]
         if d.rows <= 2000:
             cmd += ["--check-analyze"]
         subprocess.run(cmd, check=True)
         meta = json.load(open(out + ".json"))
         meta["recipe"] = {"fn": fn, "kwargs": kw}
+        if name in R_OPEN:
+            meta["r_open"] = R_OPEN[name]
         meta["generator"] = "scripts/make_golden.py via oracle/_ref/ref_driver (real reference)"
         json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
         os.replace(out + ".bin", os.path.join(GOLD, name + ".bin"))

@@ -29,7 +29,7 @@ def golden(name):
 
 def run_engine_case(eng, meta, deck, batch=1, overrides=None):
     """Runs the golden's analysis; returns (snapshots [nsnap][batch][rows], newton trace of instance 0, fail_step)."""
-    eng.set_options(g_min=meta["gmin"])
+    eng.set_options(g_min=meta["gmin"], r_open=meta.get("r_open", 0.0))
     eng.load_deck(deck, batch=batch, overrides=overrides)
     eng.reset()
     snaps = []

@@ -36,6 +36,53 @@ def test_golden_parity(eng, name, tol):
     assert list(trace) == meta["newton_iters"]          # same Newton trajectory as the reference, step by step
 
 
+# ---- remaining linear stampers (IAC, VCCS, VCVS, CCCS, CCVS, op-amp, transformer, switch, the four
+# generators, coupled inductors); goldens = the reference's own model tests (test/0005.models) + transient variants
+@pytest.mark.parametrize("name,tol", [
+    ("vccs_dc", LIN), ("vcvs_gain", LIN), ("cccs_dc", LIN), ("ccvs_dc", LIN), ("op_amp_follower", LIN), ("transformer_ratio", LIN),
+    ("generator_dc", LIN), ("switch_open_dc", LIN), ("switch_closed_dc", LIN), ("switch_open_ropen1e6_dc", LIN), ("generators_tr", LIN),
+    ("generators_trop", LIN), ("iac_rc_tr", LIN), ("iac_rc_dc", LIN), ("iac_rc_trop", LIN), ("coupled_l_k0_tr", LIN),
+    ("coupled_l_k09_tr", LIN), ("coupled_l_k09_trop", LIN), ("coupled_l_dc", LIN), ("controlled_mix_tr", NL),
+])
+def test_stamper_golden_parity(eng, name, tol):
+    meta, gx, deck = golden(name)
+    snaps, trace, fail = run_engine_case(eng, meta, deck)
+    assert fail == -1 and meta["fail_step"] == -1
+    assert len(snaps) == len(gx)
+    assert max_err(snaps[:, 0, :], gx, *tol) <= 1.0
+    assert list(trace) == meta["newton_iters"]
+
+
+def test_switch_toggle_and_param_updates(eng):
+    """test/0005.models/cutthrough.cpp idea: the same resident circuit, switch opened / closed through update_param;
+    a controlled source's gain and a generator's level changed the same way."""
+    d = pe.deck.Deck()
+    d.n_nodes = 4
+    d.add("VDC", (1, 0), 2.0)
+    d.add("SW", (1, 2), 0.0)
+    d.add("R", (2, 0), 1000.0)
+    d.add("VCVS", (3, 0, 2, 0), 3.0)
+    d.add("R", (3, 0), 500.0)
+    d.add("SQR", (4, 0), 4.0, 1.0, 1e3, 0.5, 0.0)
+    d.add("R", (4, 0), 100.0)
+    eng.set_options(g_min=0.0)
+    eng.load_deck(d)
+    eng.reset()
+    eng.analyze_dc(pe.ffi.MODE_DC)
+    x = eng.solution()[0]
+    assert abs(x[1] - 2.0 * 1000.0 / (1e12 + 1000.0)) < 1e-15 and abs(x[3] - 4.0) < 1e-12      # open: r_open 1e12
+    eng.update_param(pe.ffi.SWITCH, 0, 0, [1.0])
+    eng.update_param(pe.ffi.VCVS, 0, 0, [-1.5])
+    eng.update_param(pe.ffi.VGEN, 0, 1, [7.0])                                              # column 1 = Vh
+    eng.analyze_dc(pe.ffi.MODE_DC)
+    x = eng.solution()[0]
+    assert abs(x[1] - 2.0) < 1e-12 and abs(x[2] + 3.0) < 1e-12 and abs(x[3] - 7.0) < 1e-12
+    eng.set_options(g_min=0.0, r_open=1e6)
+    eng.update_param(pe.ffi.SWITCH, 0, 0, [0.0])
+    eng.analyze_dc(pe.ffi.MODE_DC)
+    assert abs(eng.solution()[0][1] - 2.0 * 1000.0 / (1e6 + 1000.0)) < 1e-12
+
+
 def test_bridge_gmin0_fails_like_reference(eng):
     """g_min = 0: the bridge becomes singular when all four diodes are off; the reference gives up at step 80.
     The step at which a near-singular pivot breaks Newton is implementation-defined: accept 76..82, and identical

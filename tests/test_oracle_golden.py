@@ -9,10 +9,14 @@ from parity_common import golden
 
 FAST = ["rc_step", "rl_step", "rlc_series_vl", "rlc_series_vl_trop", "divider_dc", "diode_op", "pn_tt_tr", "ladder_c1", "bridge_c2",
         "mesh32_lin", "mesh32_nl", "mesh32_lin_seed3", "mesh32_nl_seed7"]
+# the remaining linear stampers (goldens from the reference's own model tests + transient variants)
+STAMPERS = ["vccs_dc", "vcvs_gain", "cccs_dc", "ccvs_dc", "op_amp_follower", "transformer_ratio", "generator_dc", "switch_open_dc",
+            "switch_closed_dc", "switch_open_ropen1e6_dc", "generators_tr", "generators_trop", "iac_rc_tr", "iac_rc_dc", "iac_rc_trop",
+            "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop", "coupled_l_dc", "controlled_mix_tr"]
 
 
 def run_oracle(orc, meta, deck):
-    o = orc.Oracle(deck, g_min=meta["gmin"])
+    o = orc.Oracle(deck, g_min=meta["gmin"], r_open=meta.get("r_open", 0.0))
     if meta["analysis"] in ("DC", "OP"):
         o.analyze_dc(meta["analysis"])
         return o, np.array([o.x])
@@ -20,7 +24,7 @@ def run_oracle(orc, meta, deck):
     return o, np.array([out[s] for s in meta["snap_steps"] if s in out])
 
 
-@pytest.mark.parametrize("name", FAST)
+@pytest.mark.parametrize("name", FAST + STAMPERS)
 def test_oracle_matches_reference_golden(oracle_mod, name):
     meta, gx, deck = golden(name)
     o, xs = run_oracle(oracle_mod, meta, deck)
