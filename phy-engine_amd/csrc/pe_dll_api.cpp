@@ -25,6 +25,7 @@ namespace
     bool add_element(pe::netlist::netlist& nl, int code, double const*& prop, pe::netlist::add_model_retstr& out)
     {
         using namespace pe::model;
+        auto take = [&]() { return *prop++; };
         switch(code)
         {
             case 1: out = add_model(nl, resistance{.r = *prop++}); return true;
@@ -55,6 +56,56 @@ namespace
                 return true;
             }
             case 54: out = add_model(nl, full_bridge_rectifier{}); return true;
+            // ---- SURVEY.md 8f rank 1 (dll_api.h:60-97): properties consumed positionally, in the order of the header comment
+            case 7:
+            {
+                // IAC{Ip, f[Hz], phase[deg]}, same unit conversion as VAC
+                double const ip = take(), hz = take(), deg = take();
+                out = add_model(nl, IAC{.m_Ip = ip, .m_omega = 2.0 * std::numbers::pi * hz, .m_phase = deg * std::numbers::pi / 180.0});
+                return true;
+            }
+            case 8: out = add_model(nl, VCCS{.m_g = take()}); return true;
+            case 9: out = add_model(nl, VCVS{.m_mu = take()}); return true;
+            case 10: out = add_model(nl, CCCS{.m_alpha = take()}); return true;
+            case 11: out = add_model(nl, CCVS{.m_r = take()}); return true;
+            case 12: out = add_model(nl, single_pole_switch{.cut_through = take() != 0.0}); return true;
+            case 14: out = add_model(nl, transformer{.n = take()}); return true;
+            case 15:
+            {
+                coupled_inductors kl{};
+                for(double* f: {&kl.L1, &kl.L2, &kl.k}) *f = take();
+                out = add_model(nl, kl);
+                return true;
+            }
+            case 17: out = add_model(nl, op_amp{.mu = take()}); return true;
+            case 20:
+            {
+                sawtooth_gen g{};
+                for(double* f: {&g.Vh, &g.Vl, &g.freq, &g.phase}) *f = take();
+                out = add_model(nl, g);
+                return true;
+            }
+            case 21:
+            {
+                square_gen g{};
+                for(double* f: {&g.Vh, &g.Vl, &g.freq, &g.duty, &g.phase}) *f = take();
+                out = add_model(nl, g);
+                return true;
+            }
+            case 22:
+            {
+                pulse_gen g{};
+                for(double* f: {&g.Vh, &g.Vl, &g.freq, &g.duty, &g.phase, &g.tr, &g.tf}) *f = take();
+                out = add_model(nl, g);
+                return true;
+            }
+            case 23:
+            {
+                triangle_gen g{};
+                for(double* f: {&g.Vh, &g.Vl, &g.freq, &g.phase}) *f = take();
+                out = add_model(nl, g);
+                return true;
+            }
             default: return false;
         }
     }

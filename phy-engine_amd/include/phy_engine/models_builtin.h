@@ -2,6 +2,9 @@
 // netlist-building code is source compatible, and the additive gpu_table_define hook instead of host stamping.
 //   resistance / capacitor / inductor / VDC / VAC / IDC      model/models/linear/*.h
 //   PN_junction / full_bridge_rectifier                      model/models/non-linear/*.h
+//   IAC / VCCS / VCVS / CCCS / CCVS / op_amp / transformer / coupled_inductors   model/models/linear/*.h
+//   single_pole_switch                                       model/models/controller/switch.h
+//   sawtooth_gen / square_gen / pulse_gen / triangle_gen     model/models/generator/*.h
 // The numerics these rows stand for are implemented ONCE, on the device: phy-engine_amd/csrc/pe_front.hpp
 // (companion_update / eval_devices), citing the reference lines they follow.
 #pragma once
@@ -249,4 +252,345 @@ namespace phy_engine::model
 
     static_assert(model<resistance> && model<capacitor> && model<inductor> && model<VDC> && model<VAC> && model<IDC> && model<PN_junction> && model<full_bridge_rectifier>);
     static_assert(defines::can_gpu_table<resistance> && defines::can_generate_branch_view<VDC> && !defines::can_generate_branch_view<resistance>);
+
+    // =================================================================== SURVEY.md 8f rank 1: remaining linear stampers
+    namespace details
+    {
+        // single-double-attribute boilerplate shared by the controlled sources
+        template <typename M>
+        inline bool set1(double M::*f, M& m, ::std::size_t n, variant vi) noexcept { return n == 0 && set_d(f, m, vi); }
+        inline constexpr double two_pi{6.283185307179586476925286766559};
+        inline constexpr double deg{0.017453292519943295769236907684886};
+    }  // namespace details
+
+    // ------------------------------------------------------------------ IAC (linear/IAC.h): attributes Ip, freq [Hz], phase [deg]
+    struct IAC
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"IAC"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"IAC"};
+        double m_Ip{0.2};
+        double m_omega{50.0};
+        double m_phase{0.0};
+        pin pins[2]{{{u8"+"}}, {{u8"-"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<IAC>, IAC& m, ::std::size_t n, variant vi) noexcept
+    {
+        if(vi.type != variant_type::d || n > 2) return false;
+        if(n == 0) m.m_Ip = vi.d;
+        else if(n == 1)
+            m.m_omega = vi.d * details::two_pi;   // IAC.h:42
+        else
+            m.m_phase = vi.d * details::deg;      // IAC.h:48
+        return true;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<IAC>, IAC const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.m_Ip) : n == 1 ? details::dvar(m.m_omega / details::two_pi) : n == 2 ? details::dvar(m.m_phase / details::deg) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<IAC>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[3] = {u8"Ip", u8"freq", u8"phase"};
+        return n < 3 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<IAC>, IAC& m) noexcept { return {m.pins, 2}; }
+    inline bool gpu_table_define(model_reserve_type_t<IAC>, IAC const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_IAC, 0, 1, -1, {m.m_Ip, m.m_omega, m.m_phase}};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ the four controlled sources (pins S, T, P, Q):
+    // VCCS.h (no branch), VCVS.h (1 branch), CCCS.h (1 branch: the sensing short), CCVS.h (2 branches: output, sense)
+    struct VCCS
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"VCCS"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"VCCS"};
+        double m_g{1.0};
+        pin pins[4]{{{u8"S"}}, {{u8"T"}}, {{u8"P"}}, {{u8"Q"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<VCCS>, VCCS& m, ::std::size_t n, variant vi) noexcept { return details::set1(&VCCS::m_g, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<VCCS>, VCCS const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.m_g) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<VCCS>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"G"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<VCCS>, VCCS& m) noexcept { return {m.pins, 4}; }
+    inline bool gpu_table_define(model_reserve_type_t<VCCS>, VCCS const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_VCCS, 0, 1, -1, {m.m_g}, 2, 3, -1};
+        return true;
+    }
+
+    struct VCVS
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"VCVS"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"VCVS"};
+        double m_mu{1.0};
+        pin pins[4]{{{u8"S"}}, {{u8"T"}}, {{u8"P"}}, {{u8"Q"}}};
+        branch branches{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<VCVS>, VCVS& m, ::std::size_t n, variant vi) noexcept { return details::set1(&VCVS::m_mu, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<VCVS>, VCVS const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.m_mu) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<VCVS>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"Mu"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<VCVS>, VCVS& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<VCVS>, VCVS& m) noexcept { return {&m.branches, 1}; }
+    inline bool gpu_table_define(model_reserve_type_t<VCVS>, VCVS const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_VCVS, 0, 1, 0, {m.m_mu}, 2, 3, -1};
+        return true;
+    }
+
+    struct CCCS
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"CCCS"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"CCCS"};
+        double m_alpha{1.0};
+        pin pins[4]{{{u8"S"}}, {{u8"T"}}, {{u8"P"}}, {{u8"Q"}}};
+        branch branches{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<CCCS>, CCCS& m, ::std::size_t n, variant vi) noexcept { return details::set1(&CCCS::m_alpha, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<CCCS>, CCCS const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.m_alpha) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<CCCS>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"alpha"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<CCCS>, CCCS& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<CCCS>, CCCS& m) noexcept { return {&m.branches, 1}; }
+    inline bool gpu_table_define(model_reserve_type_t<CCCS>, CCCS const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_CCCS, 0, 1, 0, {m.m_alpha}, 2, 3, -1};
+        return true;
+    }
+
+    struct CCVS
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"CCVS"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"CCVS"};
+        double m_r{10.0};
+        pin pins[4]{{{u8"S"}}, {{u8"T"}}, {{u8"P"}}, {{u8"Q"}}};
+        branch branches[2]{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<CCVS>, CCVS& m, ::std::size_t n, variant vi) noexcept { return details::set1(&CCVS::m_r, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<CCVS>, CCVS const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.m_r) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<CCVS>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"r"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<CCVS>, CCVS& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<CCVS>, CCVS& m) noexcept { return {m.branches, 2}; }
+    inline bool gpu_table_define(model_reserve_type_t<CCVS>, CCVS const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_CCVS, 0, 1, 0, {m.m_r}, 2, 3, 1};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ op_amp (linear/op_amp.h): pins +, -, OUT+, OUT-
+    struct op_amp
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"OpAmp"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"OPAMP"};
+        double mu{1e5};
+        pin pins[4]{{{u8"+"}}, {{u8"-"}}, {{u8"OUT+"}}, {{u8"OUT-"}}};
+        branch branches{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<op_amp>, op_amp& m, ::std::size_t n, variant vi) noexcept { return details::set1(&op_amp::mu, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<op_amp>, op_amp const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.mu) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<op_amp>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"mu"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<op_amp>, op_amp& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<op_amp>, op_amp& m) noexcept { return {&m.branches, 1}; }
+    inline bool gpu_table_define(model_reserve_type_t<op_amp>, op_amp const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_OPAMP, 0, 1, 0, {m.mu}, 2, 3, -1};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ transformer (linear/transformer.h): pins P, Q, S, T; n = Vp / Vs
+    struct transformer
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Transformer"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"TX"};
+        double n{1.0};
+        pin pins[4]{{{u8"P"}}, {{u8"Q"}}, {{u8"S"}}, {{u8"T"}}};
+        branch branches[2]{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<transformer>, transformer& m, ::std::size_t n, variant vi) noexcept { return details::set1(&transformer::n, m, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<transformer>, transformer const& m, ::std::size_t n) noexcept { return n == 0 ? details::dvar(m.n) : variant{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<transformer>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"n"} : ::fast_io::u8string_view{}; }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<transformer>, transformer& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<transformer>, transformer& m) noexcept { return {m.branches, 2}; }
+    inline bool gpu_table_define(model_reserve_type_t<transformer>, transformer const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_XFMR, 0, 1, 0, {m.n}, 2, 3, 1};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ coupled_inductors (linear/coupled_inductors.h)
+    struct coupled_inductors
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Coupled Inductors"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"K"};
+        double L1{1e-3};
+        double L2{1e-3};
+        double k{0.99};
+        pin pins[4]{{{u8"P1"}}, {{u8"P2"}}, {{u8"S1"}}, {{u8"S2"}}};
+        branch branches[2]{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<coupled_inductors>, coupled_inductors& m, ::std::size_t n, variant vi) noexcept
+    {
+        double coupled_inductors::* const f[3] = {&coupled_inductors::L1, &coupled_inductors::L2, &coupled_inductors::k};
+        return n < 3 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<coupled_inductors>, coupled_inductors const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.L1) : n == 1 ? details::dvar(m.L2) : n == 2 ? details::dvar(m.k) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<coupled_inductors>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[3] = {u8"L1", u8"L2", u8"k"};
+        return n < 3 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<coupled_inductors>, coupled_inductors& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<coupled_inductors>, coupled_inductors& m) noexcept { return {m.branches, 2}; }
+    inline bool gpu_table_define(model_reserve_type_t<coupled_inductors>, coupled_inductors const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_COUPLED_L, 0, 1, 0, {m.L1, m.L2, m.k}, 2, 3, 1};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ single_pole_switch (controller/switch.h)
+    struct single_pole_switch
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"switch"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"switch"};
+        bool cut_through{};
+        pin pins[2]{{{u8"A"}}, {{u8"B"}}};
+        branch branches{};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<single_pole_switch>, single_pole_switch& m, ::std::size_t n, variant vi) noexcept
+    {
+        if(n != 0 || vi.type != variant_type::boolean) return false;
+        m.cut_through = vi.boolean;
+        return true;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<single_pole_switch>, single_pole_switch const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::bvar(m.cut_through) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<single_pole_switch>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"cut_through"} : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<single_pole_switch>, single_pole_switch& m) noexcept { return {m.pins, 2}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<single_pole_switch>, single_pole_switch& m) noexcept { return {&m.branches, 1}; }
+    inline bool gpu_table_define(model_reserve_type_t<single_pole_switch>, single_pole_switch const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_SWITCH, 0, 1, 0, {m.cut_through ? 1.0 : 0.0}};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ the four waveform generators (generator/*.h)
+    struct sawtooth_gen
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Sawtooth Wave Generator"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"SAW"};
+        double Vh{5.0};
+        double Vl{0.0};
+        double freq{1e3};
+        double phase{0.0};  // radians
+        pin pins[2]{{{u8"+"}}, {{u8"-"}}};
+        branch branches{};
+    };
+    struct square_gen
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Square Wave Generator"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"SQ"};
+        double Vh{5.0};
+        double Vl{0.0};
+        double freq{1e3};
+        double duty{0.5};
+        double phase{0.0};
+        pin pins[2]{{{u8"+"}}, {{u8"-"}}};
+        branch branches{};
+    };
+    struct pulse_gen
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Pulse Wave Generator"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"PULSE"};
+        double Vh{5.0};
+        double Vl{0.0};
+        double freq{1e3};
+        double duty{0.5};
+        double phase{0.0};
+        double tr{0.0};
+        double tf{0.0};
+        pin pins[2]{{{u8"+"}}, {{u8"-"}}};
+        branch branches{};
+    };
+    struct triangle_gen
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Triangle Wave Generator"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"TRIANGLE"};
+        double Vh{5.0};
+        double Vl{0.0};
+        double freq{1e3};
+        double phase{0.0};
+        pin pins[2]{{{u8"+"}}, {{u8"-"}}};
+        branch branches{};
+    };
+    namespace details
+    {
+        template <typename G, ::std::size_t N>
+        inline bool gen_set(G& g, double G::* const (&f)[N], ::std::size_t n, variant vi) noexcept { return n < N && set_d(f[n], g, vi); }
+        template <typename G, ::std::size_t N>
+        inline variant gen_get(G const& g, double G::* const (&f)[N], ::std::size_t n) noexcept { return n < N ? dvar(g.*f[n]) : variant{}; }
+    }  // namespace details
+#define PE_GENERATOR(NAME, TYPE, NATTR, FIELDS, NAMES, ROWPARAMS)                                                                                       \
+    inline bool set_attribute_define(model_reserve_type_t<NAME>, NAME& m, ::std::size_t n, variant vi) noexcept                                        \
+    {                                                                                                                                                  \
+        double NAME::* const f[NATTR] = FIELDS;                                                                                                        \
+        return details::gen_set(m, f, n, vi);                                                                                                          \
+    }                                                                                                                                                  \
+    inline variant get_attribute_define(model_reserve_type_t<NAME>, NAME const& m, ::std::size_t n) noexcept                                          \
+    {                                                                                                                                                  \
+        double NAME::* const f[NATTR] = FIELDS;                                                                                                        \
+        return details::gen_get(m, f, n);                                                                                                              \
+    }                                                                                                                                                  \
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<NAME>, ::std::size_t n) noexcept                                   \
+    {                                                                                                                                                  \
+        constexpr ::fast_io::u8string_view names[NATTR] = NAMES;                                                                                       \
+        return n < NATTR ? names[n] : ::fast_io::u8string_view{};                                                                                     \
+    }                                                                                                                                                  \
+    inline pin_view generate_pin_view_define(model_reserve_type_t<NAME>, NAME& m) noexcept { return {m.pins, 2}; }                                    \
+    inline branch_view generate_branch_view_define(model_reserve_type_t<NAME>, NAME& m) noexcept { return {&m.branches, 1}; }                         \
+    inline bool gpu_table_define(model_reserve_type_t<NAME>, NAME const& m, gpu_table_rows& t) noexcept                                               \
+    {                                                                                                                                                  \
+        t.count = 1;                                                                                                                                   \
+        t.row[0] = {PE_HIP_VGEN, 0, 1, 0, ROWPARAMS};                                                                                                  \
+        return true;                                                                                                                                   \
+    }
+#define PE_L(...) {__VA_ARGS__}
+    // PE_HIP_VGEN columns: type, Vh, Vl, freq, duty, phase, tr, tf
+    PE_GENERATOR(sawtooth_gen, 0, 4, PE_L(&sawtooth_gen::Vh, &sawtooth_gen::Vl, &sawtooth_gen::freq, &sawtooth_gen::phase), PE_L(u8"Vh", u8"Vl", u8"freq", u8"phase"),
+                 PE_L(0.0, m.Vh, m.Vl, m.freq, 0.5, m.phase, 0.0, 0.0))
+    PE_GENERATOR(square_gen, 1, 5, PE_L(&square_gen::Vh, &square_gen::Vl, &square_gen::freq, &square_gen::duty, &square_gen::phase),
+                 PE_L(u8"Vh", u8"Vl", u8"freq", u8"duty", u8"phase"), PE_L(1.0, m.Vh, m.Vl, m.freq, m.duty, m.phase, 0.0, 0.0))
+    PE_GENERATOR(pulse_gen, 2, 7, PE_L(&pulse_gen::Vh, &pulse_gen::Vl, &pulse_gen::freq, &pulse_gen::duty, &pulse_gen::phase, &pulse_gen::tr, &pulse_gen::tf),
+                 PE_L(u8"Vh", u8"Vl", u8"freq", u8"duty", u8"phase", u8"tr", u8"tf"), PE_L(2.0, m.Vh, m.Vl, m.freq, m.duty, m.phase, m.tr, m.tf))
+    PE_GENERATOR(triangle_gen, 3, 4, PE_L(&triangle_gen::Vh, &triangle_gen::Vl, &triangle_gen::freq, &triangle_gen::phase), PE_L(u8"Vh", u8"Vl", u8"freq", u8"phase"),
+                 PE_L(3.0, m.Vh, m.Vl, m.freq, 0.5, m.phase, 0.0, 0.0))
+#undef PE_L
+#undef PE_GENERATOR
 }  // namespace phy_engine::model

@@ -281,9 +281,43 @@ namespace phy_engine
         {
             int kind{};               // pe_hip_kind
             int pin_a{}, pin_b{};     // indices into the model's pin view
-            int branch{-1};           // index into the model's branch view (L / VDC / VAC), else -1
+            int branch{-1};           // index into the model's branch view (kinds with a branch row), else -1
             double params[PE_HIP_DIODE_NPARAM]{};
+            int pin_c{-1}, pin_d{-1}; // third / fourth pin of the four-pin kinds (pe_hip.h)
+            int branch2{-1};          // second branch row of the two-branch kinds
         };
+        // node / branch / parameter columns per device of a pe_hip_kind (pe_hip.h)
+        inline constexpr int gpu_kind_pins(int k) noexcept { return (k <= PE_HIP_IAC || k == PE_HIP_SWITCH || k == PE_HIP_VGEN) ? 2 : 4; }
+        inline constexpr int gpu_kind_branches(int k) noexcept
+        {
+            switch(k)
+            {
+                case PE_HIP_L:
+                case PE_HIP_VDC:
+                case PE_HIP_VAC:
+                case PE_HIP_VCVS:
+                case PE_HIP_CCCS:
+                case PE_HIP_OPAMP:
+                case PE_HIP_SWITCH:
+                case PE_HIP_VGEN: return 1;
+                case PE_HIP_CCVS:
+                case PE_HIP_XFMR:
+                case PE_HIP_COUPLED_L: return 2;
+                default: return 0;
+            }
+        }
+        inline constexpr int gpu_kind_ncol(int k) noexcept
+        {
+            switch(k)
+            {
+                case PE_HIP_VAC:
+                case PE_HIP_IAC:
+                case PE_HIP_COUPLED_L: return 3;
+                case PE_HIP_DIODE: return PE_HIP_DIODE_NPARAM;
+                case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
+                default: return 1;
+            }
+        }
         struct gpu_table_rows
         {
             gpu_table_row row[4]{};
@@ -892,8 +926,14 @@ namespace phy_engine
                         auto& t = next.kind[row.kind];
                         t.nodes.push_back(node_id(row.pin_a));
                         t.nodes.push_back(node_id(row.pin_b));
+                        if(model::gpu_kind_pins(row.kind) == 4)
+                        {
+                            t.nodes.push_back(node_id(row.pin_c));
+                            t.nodes.push_back(node_id(row.pin_d));
+                        }
                         if(row.branch >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch);
-                        int const ncol = row.kind == PE_HIP_VAC ? 3 : (row.kind == PE_HIP_DIODE ? PE_HIP_DIODE_NPARAM : 1);
+                        if(row.branch2 >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch2);
+                        int const ncol = model::gpu_kind_ncol(row.kind);
                         for(int q = 0; q < ncol; ++q) t.params.push_back(row.params[q]);
                     }
                 }
@@ -920,6 +960,7 @@ namespace phy_engine
             o.i_abstol = env.I_eps_max;
             o.i_reltol = env.I_epsr_max;
             o.g_min = env.g_min;
+            o.r_open = env.r_open;
             o.refactor_every_solve = 1;
             if(pe_hip_set_options(gpu_, &o) != PE_HIP_OK) return gpu_fail();
 
@@ -928,11 +969,12 @@ namespace phy_engine
                 if(pe_hip_set_digital_drives(gpu_, static_cast<int>(next.drv_node.size()), next.drv_node.data(), next.drv_volt.data()) != PE_HIP_OK)
                     return gpu_fail();
                 ::std::vector<pe_hip_device_table> tabs;
-                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                for(int k = 1; k <= PE_HIP_KIND_MAX; ++k)
                 {
                     auto& t = next.kind[k];
                     if(t.nodes.empty()) continue;
-                    tabs.push_back({k, static_cast<int>(t.nodes.size() / 2), t.nodes.data(), t.branch.empty() ? nullptr : t.branch.data(), t.params.data(), 0});
+                    tabs.push_back({k, static_cast<int>(t.nodes.size()) / model::gpu_kind_pins(k), t.nodes.data(), t.branch.empty() ? nullptr : t.branch.data(),
+                                    t.params.data(), 0});
                 }
                 if(pe_hip_load_circuit(gpu_, next.n_nodes, next.n_branches, 1, static_cast<int>(tabs.size()), tabs.data()) != PE_HIP_OK) return gpu_fail();
                 loaded_ = true;
@@ -949,11 +991,11 @@ namespace phy_engine
                    pe_hip_set_digital_drives(gpu_, static_cast<int>(next.drv_node.size()), next.drv_node.data(), next.drv_volt.data()) != PE_HIP_OK)
                     return gpu_fail();
                 // same topology: push changed parameters only
-                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                for(int k = 1; k <= PE_HIP_KIND_MAX; ++k)
                 {
                     auto const& a = next.kind[k].params;
                     auto const& b = resident_.kind[k].params;
-                    int const ncol = k == PE_HIP_VAC ? 3 : (k == PE_HIP_DIODE ? PE_HIP_DIODE_NPARAM : 1);
+                    int const ncol = model::gpu_kind_ncol(k);
                     for(::std::size_t i = 0; i < a.size(); ++i)
                         if(a[i] != b[i])
                             if(pe_hip_update_param(gpu_, k, static_cast<int>(i / ncol), static_cast<int>(i % ncol), &a[i], 0) != PE_HIP_OK) return gpu_fail();
@@ -984,13 +1026,13 @@ namespace phy_engine
         struct tables_
         {
             int n_nodes{}, n_branches{};
-            table_ kind[PE_HIP_DIODE + 1]{};
+            table_ kind[PE_HIP_KIND_MAX + 1]{};
             ::std::vector<int> drv_node;
             ::std::vector<double> drv_volt;
             bool same_topology(tables_ const& o) const
             {
                 if(n_nodes != o.n_nodes || n_branches != o.n_branches || drv_node != o.drv_node) return false;
-                for(int k = 1; k <= PE_HIP_DIODE; ++k)
+                for(int k = 1; k <= PE_HIP_KIND_MAX; ++k)
                     if(kind[k].nodes != o.kind[k].nodes || kind[k].branch != o.kind[k].branch || kind[k].params.size() != o.kind[k].params.size()) return false;
                 return true;
             }
