@@ -181,6 +181,9 @@ int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind
  * [0] device eval + MNA gather, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward wave fronts,
  * [4] forward+backward cooperative fronts, [5] backward wave fronts, [6..7] reserved */
 int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8);
+/* the same plus, from slot 8 on, six values per cooperative-front layout (0 whole front in LDS, 1 pivot panels + pulled Schur
+ * tiles, 2 chain link): assembly, block loop, Schur update, factor store [ticks], fronts [count], sum of m*m */
+int pe_hip_get_phase_clocks_ex(pe_hip_engine* h, int instance, int capacity, long long* ticks, int* n_out);
 
 /* host-only: run the symbolic analysis on a pattern and report its statistics (no GPU needed) */
 int pe_hip_analyze_pattern(int n, const int* row_ptr, const int* col_ind, const double* values, pe_hip_info* out);

@@ -12,6 +12,13 @@ namespace pe
         DV_GMIN = 1,  // env.g_min (circuit.h:1107-1110)
         DV_FIXED = 2
     };
+    // in-kernel phase clocks per instance: [0] eval+stamp, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward, [4] -,
+    // [5] backward, [6] cooperative assembly, [7] cooperative block loop; then per cooperative front layout L = 0 whole-front,
+    // 1 panel+pull, 2 chain link at 8 + 6 L: assembly, block loop, Schur, store, fronts, sum of m*m
+    enum : int
+    {
+        PE_PROF = 32
+    };
 
     // diode parameter columns after host-side prepare_foundation (PN_junction.h:296-354)
     enum : int
@@ -84,6 +91,7 @@ namespace pe
         int const *f_child_ptr, *f_child;
         int const* f_rel;       // indexed through f_rows_ptr
         long long const* f_inv_off;  // per child edge (index into f_child), cooperative parents only
+        int const* f_cnp;            // per child edge: leading update rows of the child that are pivot rows of the parent
         int const* f_inv;
         int const *f_asm_ptr, *asm_slot, *asm_pos;
         long long const *f_lptr, *f_uptr, *f_sptr;

@@ -155,6 +155,7 @@ namespace
         HIPCHK(h, pool.upload(V.f_child, S.f_child));
         HIPCHK(h, pool.upload(V.f_rel, S.f_rel));
         HIPCHK(h, pool.upload(V.f_inv_off, S.f_inv_off));
+        HIPCHK(h, pool.upload(V.f_cnp, S.f_cnp));
         HIPCHK(h, pool.upload(V.f_inv, S.f_inv));
         HIPCHK(h, pool.upload(V.f_asm_ptr, S.f_asm_ptr));
         HIPCHK(h, pool.upload(V.asm_slot, S.asm_slot));
@@ -252,7 +253,7 @@ namespace
         while(static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m > lds_doubles && so.wave_m > 8) --so.wave_m;
         so.wave_p = std::min(so.wave_p, so.wave_m);
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
-        so.panel_doubles = lds_doubles;
+        so.panel_doubles = lds_doubles - 384;  // large (panel-mode) fronts keep room for their children's staged inverse maps
         return so;
     }
 
@@ -713,7 +714,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     V.trace_cap = 1 << 16;
     HIPCHK(h, P.alloc(V.trace, static_cast<size_t>(V.trace_cap)));
     HIPCHK(h, P.alloc(V.trace_len, 1));
-    HIPCHK(h, P.alloc(V.prof, B * 8));
+    HIPCHK(h, P.alloc(V.prof, B * pe::PE_PROF));
     HIPCHK(h, P.alloc(V.active, B));
     HIPCHK(h, P.alloc(V.flags, B));
     // static part of dv
@@ -805,7 +806,7 @@ int pe_hip_reset(pe_hip_engine* h)
     HIPCHK(h, hipMemset(V.n_steps, 0, B * sizeof(long long)));
     HIPCHK(h, hipMemset(V.n_iters, 0, B * sizeof(long long)));
     HIPCHK(h, hipMemset(V.trace_len, 0, sizeof(int)));
-    HIPCHK(h, hipMemset(V.prof, 0, B * 8 * sizeof(long long)));
+    HIPCHK(h, hipMemset(V.prof, 0, B * pe::PE_PROF * sizeof(long long)));
     h->fact_valid = false;
     return PE_HIP_OK;
 }
@@ -1162,7 +1163,18 @@ int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8)
 {
     if(!h || !h->loaded || !ticks8 || instance < 0 || instance >= h->hc.batch) return PE_HIP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpy(ticks8, h->V.prof + static_cast<size_t>(instance) * 8, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(ticks8, h->V.prof + static_cast<size_t>(instance) * pe::PE_PROF, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+/* all PE_PROF slots (pe_device.hpp): the eight above + per-layout breakdown of the cooperative fronts */
+int pe_hip_get_phase_clocks_ex(pe_hip_engine* h, int instance, int capacity, long long* ticks, int* n_out)
+{
+    if(!h || !h->loaded || !ticks || capacity < 0 || instance < 0 || instance >= h->hc.batch) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int const n = std::min(capacity, static_cast<int>(pe::PE_PROF));
+    HIPCHK(h, hipMemcpy(ticks, h->V.prof + static_cast<size_t>(instance) * pe::PE_PROF, n * sizeof(long long), hipMemcpyDeviceToHost));
+    if(n_out) *n_out = n;
     return PE_HIP_OK;
 }
 

@@ -489,8 +489,11 @@ namespace pe
             }
             else
             {
-                // entries of the child's update matrix that land in this front's pivot rows / columns
-                for(int base = t0; base < n; base += 4 * T)
+                // entries of the child's update matrix that land in this front's pivot columns (its first np columns: f_rel
+                // ascends, pivots come first) and pivot rows (first np rows of the other columns); nothing else is touched
+                int const np = V.f_cnp[ch];
+                int const nA = uc * np;                       // contiguous: columns 0 .. np-1
+                for(int base = t0; base < nA; base += 4 * T)
                 {
                     double v[4];
                     int d[4];
@@ -498,21 +501,38 @@ namespace pe
                     for(int q = 0; q < 4; ++q)
                     {
                         int const idx = base + q * T;
-                        d[q] = -1;
-                        v[q] = 0.0;
-                        if(idx < n)
-                        {
-                            int const j = fdiv(idx, rcp), i = idx - j * uc;
-                            int const ri = rel[i], rj = rel[j];
-                            if(rj < p) d[q] = ri + rj * m;
-                            else if(ri < p)
-                                d[q] = m * p + ri + (rj - p) * p;
-                            if(d[q] >= 0) v[q] = Sc[idx];
-                        }
+                        bool const in = idx < nA;
+                        int const ix = in ? idx : 0;
+                        v[q] = Sc[ix];
+                        int const j = fdiv(ix, rcp), i = ix - j * uc;
+                        d[q] = in ? rel[i] + rel[j] * m : -1;
                     }
 #pragma unroll
                     for(int q = 0; q < 4; ++q)
                         if(d[q] >= 0) lds[d[q]] += v[q];
+                }
+                if(np > 0)
+                {
+                    int const nB = np * (uc - np);            // rows 0 .. np-1 of columns np .. uc-1
+                    float const rnp = 1.0f / static_cast<float>(np);
+                    for(int base = t0; base < nB; base += 4 * T)
+                    {
+                        double v[4];
+                        int d[4];
+#pragma unroll
+                        for(int q = 0; q < 4; ++q)
+                        {
+                            int const idx = base + q * T;
+                            bool const in = idx < nB;
+                            int const ix = in ? idx : 0;
+                            int const jj = fdiv(ix, rnp), i = ix - jj * np, j = jj + np;
+                            v[q] = Sc[i + j * uc];
+                            d[q] = in ? m * p + rel[i] + (rel[j] - p) * p : -1;
+                        }
+#pragma unroll
+                        for(int q = 0; q < 4; ++q)
+                            if(d[q] >= 0) lds[d[q]] += v[q];
+                    }
                 }
             }
             tm.sync_lds();
@@ -642,16 +662,40 @@ namespace pe
             }
             tm.sync();
         }
+        long long const ck2 = tm.clock();
         if(profile && V.prof && t0 == 0)
         {
-            V.prof[b * 8 + 6] += ck1 - ck0;
-            V.prof[b * 8 + 7] += tm.clock() - ck1;
+            V.prof[b * PE_PROF + 6] += ck1 - ck0;
+            V.prof[b * PE_PROF + 7] += ck2 - ck1;
         }
         // Schur block: S = (children's contributions) - L21 * U12
         if(u > 0)
         {
             double* Ss = arena + V.f_sptr[s];
             int const nt = (u + 15) / 16;
+            // PANEL mode: the children's inverse maps (rows p.. of this front -> child index) are staged behind the panels
+            // when they fit, so that a tile's pulls are ONE round of unconditional loads instead of index-dependent ones
+            int const nch = ch1 - ch0;
+            long long* csp = reinterpret_cast<long long*>(lds + nlds);  // per child: arena offset of its update matrix,
+            int* cuc = reinterpret_cast<int*>(csp + nch);               //            its order,
+            int* linv = cuc + nch + (nch & 1);                          //            its inverse map (rows p.. of this front)
+            bool const staged = !full && !chain && (static_cast<long long>(nch) * (u + 3) + 2) * 4 <= static_cast<long long>(cap - nlds) * 8;
+            if(staged)
+            {
+                for(int q = t0; q < nch; q += T)
+                {
+                    int const cc = V.f_child[ch0 + q];
+                    csp[q] = V.f_sptr[cc];
+                    cuc[q] = V.f_u[cc];
+                }
+                float const ru = 1.0f / static_cast<float>(u);
+                for(int idx = t0; idx < nch * u; idx += T)
+                {
+                    int const c = fdiv(idx, ru), r = idx - c * u;
+                    linv[idx] = V.f_inv[V.f_inv_off[ch0 + c] + p + r];
+                }
+                tm.sync_lds();
+            }
             tm.for_each_wave(
                 [&](int w, int lane, int NL)
                 {
@@ -666,21 +710,45 @@ namespace pe
                             acc = tm.tile_load(arena + V.f_sptr[V.f_child[ch0]] + (p + i0) + static_cast<long long>(p + j0) * m, m, mr, nc, lane);
                         else
                         {
-                            for(int ch = ch0; ch < ch1; ++ch)
+                            if(staged)
                             {
-                                int const* inv = V.f_inv + V.f_inv_off[ch] + p;
-                                int const cc = V.f_child[ch];
-                                int const uc = V.f_u[cc];
-                                double const* Sc = arena + V.f_sptr[cc];
-                                tm.tile_foreach(acc, lane,
-                                                [&](int r, int c, double& v)
-                                                {
-                                                    if(r < mr && c < nc)
+                                // every child's metadata and inverse map come from LDS, every load from the children's
+                                // update matrices is unconditional: the loads of several children are in flight together
+#pragma unroll 4
+                                for(int q = 0; q < nch; ++q)
+                                {
+                                    int const uc = cuc[q];
+                                    double const* Sc = arena + csp[q];
+                                    int const* inv = linv + q * u;
+                                    tm.tile_foreach(acc, lane,
+                                                    [&](int r, int c, double& v)
                                                     {
-                                                        int const ci = inv[i0 + r], cj = inv[j0 + c];
-                                                        if(ci >= 0 && cj >= 0) v += Sc[ci + cj * uc];
-                                                    }
-                                                });
+                                                        bool const in = r < mr && c < nc;
+                                                        int const ci = in ? inv[i0 + r] : -1, cj = in ? inv[j0 + c] : -1;
+                                                        bool const hit = ci >= 0 && cj >= 0;
+                                                        double const sv = Sc[hit ? ci + cj * uc : 0];
+                                                        v += hit ? sv : 0.0;
+                                                    });
+                                }
+                            }
+                            else
+                            {
+                                for(int ch = ch0; ch < ch1; ++ch)
+                                {
+                                    int const cc = V.f_child[ch];
+                                    int const uc = V.f_u[cc];
+                                    double const* Sc = arena + V.f_sptr[cc];
+                                    int const* inv = V.f_inv + V.f_inv_off[ch] + p;
+                                    tm.tile_foreach(acc, lane,
+                                                    [&](int r, int c, double& v)
+                                                    {
+                                                        if(r < mr && c < nc)
+                                                        {
+                                                            int const ci = inv[i0 + r], cj = inv[j0 + c];
+                                                            if(ci >= 0 && cj >= 0) v += Sc[ci + cj * uc];
+                                                        }
+                                                    });
+                                }
                             }
                         }
                         tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
@@ -688,6 +756,7 @@ namespace pe
                     }
                 });
         }
+        long long const ck3 = tm.clock();
         double* Lg = fac + V.f_lptr[s];
         if(full)
         {
@@ -702,6 +771,16 @@ namespace pe
         else
             for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
         tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
+        if(profile && V.prof && t0 == 0)
+        {
+            long long* q = V.prof + b * PE_PROF + 8 + 6 * (full ? 0 : (chain ? 2 : 1));
+            q[0] += ck1 - ck0;
+            q[1] += ck2 - ck1;
+            q[2] += ck3 - ck2;
+            q[3] += tm.clock() - ck3;
+            q[4] += 1;
+            q[5] += m * m;
+        }
         return true;
     }
 
@@ -731,8 +810,8 @@ namespace pe
             if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, true)) return false;
         if(V.prof && tm.tid() == 0 && part == 0)
         {
-            V.prof[b * 8 + 1] += c1 - c0;
-            V.prof[b * 8 + 2] += tm.clock() - c1;
+            V.prof[b * PE_PROF + 1] += c1 - c0;
+            V.prof[b * PE_PROF + 2] += tm.clock() - c1;
         }
         return true;
     }
@@ -941,8 +1020,8 @@ namespace pe
         backward_part(tm, V, b, 0, lds);
         if(V.prof && t0 == 0)
         {
-            V.prof[b * 8 + 3] += c1 - c0;
-            V.prof[b * 8 + 5] += tm.clock() - c1;
+            V.prof[b * PE_PROF + 3] += c1 - c0;
+            V.prof[b * PE_PROF + 5] += tm.clock() - c1;
         }
         for(int k = t0; k < V.rows; k += T) x[V.col_src[k]] = w[k];
         tm.sync();
@@ -986,7 +1065,7 @@ namespace pe
             tm.sync();
             stamp(tm, V, b);
             tm.sync();
-            if(V.prof && tm.tid() == 0) V.prof[b * 8 + 0] += tm.clock() - c0;
+            if(V.prof && tm.tid() == 0) V.prof[b * PE_PROF + 0] += tm.clock() - c0;
             if(!reuse_factor)
             {
                 if(!factor_all(tm, V, b, lds)) return ST_SINGULAR;

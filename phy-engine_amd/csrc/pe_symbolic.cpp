@@ -970,6 +970,7 @@ namespace pe
         }
         // inverse relative maps of every parent front
         S.f_inv_off.assign(S.f_child.size(), -1);
+        S.f_cnp.assign(S.f_child.size(), 0);
         S.f_inv.clear();
         S.wave_panel_doubles = 1;
         for(int s = 0; s < nf; ++s)
@@ -983,6 +984,9 @@ namespace pe
                 S.f_inv.resize(S.f_inv.size() + m, -1);
                 int* inv = S.f_inv.data() + S.f_inv_off[a];
                 for(int i = 0; i < S.f_u[c]; ++i) inv[S.f_rel[S.f_rows_ptr[c] + i]] = i;
+                int np = 0;
+                while(np < S.f_u[c] && S.f_rel[S.f_rows_ptr[c] + np] < S.f_p[s]) ++np;
+                S.f_cnp[a] = np;
             }
         }
         return true;

@@ -70,6 +70,7 @@ namespace pe
         // pull-based assembly of the Schur blocks: for child edge e (position in f_child),
         // f_inv[f_inv_off[e] + r] = index of parent-local row r among the child's update rows, or -1
         std::vector<long long> f_inv_off;
+        std::vector<int> f_cnp;                 // per child edge: how many of the child's update rows are pivots of the parent (a prefix: f_rel ascends)
         std::vector<int> f_inv;
         int max_m{};                            // largest front order
         int max_u{};

@@ -25,7 +25,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
-    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_set_time",
+    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_set_time",
 ]
 
 
@@ -315,6 +315,19 @@ class Engine:
         self._chk(fn(self._h, instance, t.ctypes.data_as(C.POINTER(C.c_longlong))))
         names = ["eval_stamp", "lu_wave", "lu_coop", "forward", "unused", "backward", "coop_asm", "coop_piv"]
         return {n: float(t[i]) / 100.0 for i, n in enumerate(names)}
+
+    def phase_clocks_coop(self, instance=0):
+        """Per-layout breakdown of the cooperative fronts (see pe_hip_get_phase_clocks_ex), microseconds / counts."""
+        t = np.zeros(32, dtype=np.int64)
+        n = C.c_int()
+        fn = lib().pe_hip_get_phase_clocks_ex
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        self._chk(fn(self._h, instance, 32, t.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(n)))
+        out = {}
+        for L, name in enumerate(("whole", "panel", "chain")):
+            q = t[8 + 6 * L: 14 + 6 * L]
+            out[name] = {"asm": q[0] / 100.0, "piv": q[1] / 100.0, "schur": q[2] / 100.0, "store": q[3] / 100.0, "fronts": int(q[4]), "sum_m2": int(q[5])}
+        return out
 
     def update_param(self, kind, index, column, values):
         v = np.atleast_1d(np.asarray(values, dtype=np.float64))
