@@ -66,12 +66,17 @@ enum pe_hip_kind
     PE_HIP_VGEN = 16,  /* nodes +,-     +1 br params: type, Vh, Vl, freq[Hz], duty, phase[rad], tr, tf
                                               type 0 sawtooth, 1 square, 2 pulse, 3 triangle; OP/DC/TROP take t = 0
                                               (generator/sawtooth.h:88-107, square.h:93-110, pulse.h:107-141, triangle.h:88-112) */
-    PE_HIP_COUPLED_L = 17 /* nodes p1,p2,s1,s2 +2 br params: L1, L2, k  trapezoidal 2x2 Thevenin companion in TR, two
+    PE_HIP_COUPLED_L = 17,/* nodes p1,p2,s1,s2 +2 br params: L1, L2, k  trapezoidal 2x2 Thevenin companion in TR, two
                                               shorts otherwise (linear/coupled_inductors.h:92-115,160-246) */
+    /* three-pin non-linear devices: nodes [count][3]; re-linearised every Newton iteration on the device */
+    PE_HIP_NMOS = 18,     /* nodes D,G,S  params: Kp, lambda, Vth   Shichman-Hodges level 1 (non-linear/nmosfet.h:84-141) */
+    PE_HIP_PMOS = 19,     /* nodes D,G,S  params: Kp, lambda, Vth                          (non-linear/pmosfet.h:84-139) */
+    PE_HIP_BJT_NPN = 20,  /* nodes B,C,E  params: Is, N, BetaF, Temp, Area   forward-active Ebers-Moll (non-linear/BJT_NPN.h:100-158) */
+    PE_HIP_BJT_PNP = 21   /* nodes B,C,E  params: Is, N, BetaF, Temp, Area                  (non-linear/BJT_PNP.h:100-158) */
 };
 #define PE_HIP_DIODE_NPARAM 11
 #define PE_HIP_VGEN_NPARAM 8
-#define PE_HIP_KIND_MAX 17
+#define PE_HIP_KIND_MAX 21
 
 /* analysis modes (phy_engine::analyze_type, circuits/analyze.h:7-16) */
 enum pe_hip_mode
@@ -86,7 +91,7 @@ typedef struct pe_hip_device_table
 {
     int kind;             /* pe_hip_kind */
     int count;            /* devices in this table */
-    const int* nodes;     /* [count][pins] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin (pins = 2, or 4: see pe_hip_kind) */
+    const int* nodes;     /* [count][pins] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin (pins = 2, 3 or 4: see pe_hip_kind) */
     const int* branch;    /* [count][branches] global branch index (0-based, after digital drives) for kinds with branch rows, else NULL */
     const double* params; /* [batch][count][ncol] when params_batched, else [count][ncol] (shared by every instance) */
     int params_batched;

@@ -45,6 +45,10 @@
 #include <phy_engine/model/models/generator/square.h>
 #include <phy_engine/model/models/generator/pulse.h>
 #include <phy_engine/model/models/generator/triangle.h>
+#include <phy_engine/model/models/non-linear/nmosfet.h>
+#include <phy_engine/model/models/non-linear/pmosfet.h>
+#include <phy_engine/model/models/non-linear/BJT_NPN.h>
+#include <phy_engine/model/models/non-linear/BJT_PNP.h>
 #include <phy_engine/model/models/non-linear/PN_junction.h>
 #include <phy_engine/model/models/non-linear/full_bridge_rectifier.h>
 #include <phy_engine/netlist/impl.h>
@@ -67,6 +71,7 @@ struct deck
 static int n_pins_of(std::string const& k)
 {
     if(k == "FBR" || k == "VCCS" || k == "VCVS" || k == "CCCS" || k == "CCVS" || k == "OPAMP" || k == "XFMR" || k == "KL") return 4;
+    if(k == "NMOS" || k == "PMOS" || k == "NPN" || k == "PNP") return 3;
     return 2;
 }
 
@@ -148,6 +153,12 @@ static bool build(pe::circult& c, deck const& d)
         else if(l.kind == "PULSE")
             m = add_model(nl, pe::model::pulse_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .duty = P(3, 0.5), .phase = P(4, 0.0), .tr = P(5, 0.0), .tf = P(6, 0.0)}).mod;
         else if(l.kind == "TRI") m = add_model(nl, pe::model::triangle_gen{.Vh = P(0, 5.0), .Vl = P(1, 0.0), .freq = P(2, 1e3), .phase = P(3, 0.0)}).mod;
+        else if(l.kind == "NMOS") m = add_model(nl, pe::model::nmosfet{.Kp = P(0, 1e-3), .lambda = P(1, 0.0), .Vth = P(2, 1.0)}).mod;
+        else if(l.kind == "PMOS") m = add_model(nl, pe::model::pmosfet{.Kp = P(0, 1e-3), .lambda = P(1, 0.0), .Vth = P(2, 1.0)}).mod;
+        else if(l.kind == "NPN")
+            m = add_model(nl, pe::model::BJT_NPN{.Is = P(0, 1e-16), .N = P(1, 1.0), .BetaF = P(2, 100.0), .Temp = P(3, 27.0), .Area = P(4, 1.0)}).mod;
+        else if(l.kind == "PNP")
+            m = add_model(nl, pe::model::BJT_PNP{.Is = P(0, 1e-16), .N = P(1, 1.0), .BetaF = P(2, 100.0), .Temp = P(3, 27.0), .Area = P(4, 1.0)}).mod;
         else if(l.kind == "KL") m = add_model(nl, pe::model::coupled_inductors{.L1 = P(0, 1e-3), .L2 = P(1, 1e-3), .k = P(2, 0.99)}).mod;
         else
         {

@@ -19,13 +19,21 @@ namespace pe
         inline int row_of(int node_id) { return node_id == 0 ? -1 : node_id - 1; }
     }  // namespace
 
-    int gen_pins(int kind) { return (kind == PE_HIP_IAC || kind == PE_HIP_SWITCH || kind == PE_HIP_VGEN) ? 2 : 4; }
+    int gen_pins(int kind)
+    {
+        if(kind >= PE_HIP_NMOS) return 3;
+        return (kind == PE_HIP_IAC || kind == PE_HIP_SWITCH || kind == PE_HIP_VGEN) ? 2 : 4;
+    }
     int gen_branches(int kind)
     {
         switch(kind)
         {
             case PE_HIP_IAC:
-            case PE_HIP_VCCS: return 0;
+            case PE_HIP_VCCS:
+            case PE_HIP_NMOS:
+            case PE_HIP_PMOS:
+            case PE_HIP_BJT_NPN:
+            case PE_HIP_BJT_PNP: return 0;
             case PE_HIP_CCVS:
             case PE_HIP_XFMR:
             case PE_HIP_COUPLED_L: return 2;
@@ -37,12 +45,22 @@ namespace pe
         switch(kind)
         {
             case PE_HIP_IAC:
-            case PE_HIP_COUPLED_L: return 3;
+            case PE_HIP_COUPLED_L:
+            case PE_HIP_NMOS:
+            case PE_HIP_PMOS: return 3;
+            case PE_HIP_BJT_NPN:
+            case PE_HIP_BJT_PNP: return 5;
             case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
             default: return 1;
         }
     }
-    int gen_ndv(int kind) { return kind == PE_HIP_COUPLED_L ? 5 : 1; }
+    int gen_ndv(int kind)
+    {
+        if(kind == PE_HIP_COUPLED_L) return 5;
+        if(kind == PE_HIP_NMOS || kind == PE_HIP_PMOS) return 3;
+        if(kind == PE_HIP_BJT_NPN || kind == PE_HIP_BJT_PNP) return 4;
+        return 1;
+    }
     bool gen_static_value(int kind, double const* raw, double r_open, double& out)
     {
         switch(kind)
@@ -75,6 +93,23 @@ namespace pe
         {
             double* o = &hc.cl_par[(static_cast<size_t>(b) * hc.nCl() + d.aux) * 3];
             for(int c = 0; c < 3; ++c) o[c] = raw[c];
+        }
+        else if(d.kind == PE_HIP_NMOS || d.kind == PE_HIP_PMOS)
+        {
+            double* o = &hc.n3_par[(static_cast<size_t>(b) * hc.nN3() + d.aux) * 3];
+            for(int c = 0; c < 3; ++c) o[c] = raw[c];
+        }
+        else if(d.kind == PE_HIP_BJT_NPN || d.kind == PE_HIP_BJT_PNP)
+        {
+            // BJT_NPN.h:100-106 (prepare_foundation) + :122-126
+            constexpr double kKelvin{-273.15};
+            constexpr double qElement{1.6021765314e-19};
+            constexpr double kBoltzmann{1.380650524e-23};
+            double const Ut = kBoltzmann * (raw[3] - kKelvin) / qElement;
+            double* o = &hc.n3_par[(static_cast<size_t>(b) * hc.nN3() + d.aux) * 3];
+            o[0] = raw[0] * raw[4];
+            o[1] = raw[1] * Ut;
+            o[2] = raw[2];
         }
     }
 
@@ -356,6 +391,13 @@ namespace pe
                 hc.ts_kind.push_back(type);
                 hc.ts_dv.push_back(0);
             }
+            else if(d.kind >= PE_HIP_NMOS)
+            {
+                d.aux = hc.nN3();
+                hc.n3_kind.push_back(d.kind);
+                for(int q = 0; q < 3; ++q) hc.n3_n.push_back(d.n[q]);
+                hc.n3_dv.push_back(0);
+            }
             else if(d.kind == PE_HIP_COUPLED_L)
             {
                 d.aux = hc.nCl();
@@ -367,6 +409,8 @@ namespace pe
         }
         hc.ts_par.assign(static_cast<size_t>(batch) * hc.nTs() * 8, 0.0);
         hc.cl_par.assign(static_cast<size_t>(batch) * hc.nCl() * 3, 0.0);
+        hc.n3_par.assign(static_cast<size_t>(batch) * hc.nN3() * 3, 0.0);
+        hc.nonlinear = hc.nonlinear || hc.nN3() > 0;
         for(size_t g = 0; g < hc.gen.size(); ++g)
             for(int inst = 0; inst < batch; ++inst) gen_derive(hc, static_cast<int>(g), inst);
 
@@ -391,6 +435,8 @@ namespace pe
             if(d.kind == PE_HIP_IAC || d.kind == PE_HIP_VGEN) hc.ts_dv[d.aux] = d.dv;
             else if(d.kind == PE_HIP_COUPLED_L)
                 hc.cl_dv[d.aux] = d.dv;
+            else if(d.kind >= PE_HIP_NMOS)
+                hc.n3_dv[d.aux] = d.dv;
         }
         hc.dv_len = o;
 
@@ -536,6 +582,46 @@ namespace pe
                     incidence(n[0], n[1], k[0]);
                     B_set(k[0], v, false);
                     break;
+                case PE_HIP_NMOS:  // nmosfet.h:124-138: gds D-S, gm (Vg - Vs) into D-S, Ieq D->S
+                    G4(n[0], n[2], v);
+                    A_add(n[0], n[1], v + 1, false);
+                    A_add(n[0], n[2], v + 1, true);
+                    A_add(n[2], n[1], v + 1, true);
+                    A_add(n[2], n[2], v + 1, false);
+                    B_add(n[0], v + 2, true);
+                    B_add(n[2], v + 2, false);
+                    break;
+                case PE_HIP_PMOS:  // pmosfet.h:122-137: control is Vs - Vg
+                    G4(n[0], n[2], v);
+                    A_add(n[0], n[2], v + 1, false);
+                    A_add(n[0], n[1], v + 1, true);
+                    A_add(n[2], n[2], v + 1, true);
+                    A_add(n[2], n[1], v + 1, false);
+                    B_add(n[0], v + 2, true);
+                    B_add(n[2], v + 2, false);
+                    break;
+                case PE_HIP_BJT_NPN:  // BJT_NPN.h:135-157 (pins B, C, E)
+                    G4(n[0], n[2], v);
+                    B_add(n[0], v + 1, true);
+                    B_add(n[2], v + 1, false);
+                    A_add(n[1], n[0], v + 2, false);
+                    A_add(n[1], n[2], v + 2, true);
+                    A_add(n[2], n[0], v + 2, true);
+                    A_add(n[2], n[2], v + 2, false);
+                    B_add(n[1], v + 3, true);
+                    B_add(n[2], v + 3, false);
+                    break;
+                case PE_HIP_BJT_PNP:  // BJT_PNP.h:135-157
+                    G4(n[2], n[0], v);
+                    B_add(n[2], v + 1, true);
+                    B_add(n[0], v + 1, false);
+                    A_add(n[2], n[2], v + 2, false);
+                    A_add(n[2], n[0], v + 2, true);
+                    A_add(n[1], n[2], v + 2, true);
+                    A_add(n[1], n[0], v + 2, false);
+                    B_add(n[2], v + 3, true);
+                    B_add(n[1], v + 3, false);
+                    break;
                 case PE_HIP_COUPLED_L:  // coupled_inductors.h:223-243 (zeros in the D / E cells reproduce the DC stamp :104-112)
                     A_set(n[0], k[0], DV_ONE, false);
                     A_set(n[1], k[0], DV_ONE, true);
@@ -621,6 +707,16 @@ namespace pe
             double const* raw = &hc.gen_par[d.par];
             double sv;
             if(gen_static_value(d.kind, raw, r_open, sv)) dv[d.dv] = sv;
+            else if(d.kind == PE_HIP_NMOS || d.kind == PE_HIP_PMOS)
+            {
+                dv[d.dv] = 1e-2 * raw[0];  // representative gds / gm of a conducting device (|Vov| ~ 10 mV .. 1 V)
+                dv[d.dv + 1] = raw[0];
+            }
+            else if(d.kind == PE_HIP_BJT_NPN || d.kind == PE_HIP_BJT_PNP)
+            {
+                dv[d.dv] = raw[0] * raw[4] / 0.025;
+                dv[d.dv + 2] = raw[2] * dv[d.dv];
+            }
             else if(d.kind == PE_HIP_COUPLED_L && dyn)
             {
                 double const M = raw[2] * std::sqrt(raw[0] * raw[1]);

@@ -59,6 +59,9 @@ namespace pe
         std::vector<double> ts_par;    // [batch][nTs][8]
         std::vector<int> cl_n, cl_k, cl_dv;
         std::vector<double> cl_par;    // [batch][nCl][3]
+        std::vector<int> n3_kind, n3_n, n3_dv;
+        std::vector<double> n3_par;    // [batch][nN3][3]
+        int nN3() const { return static_cast<int>(n3_kind.size()); }
         int nTs() const { return static_cast<int>(ts_kind.size()); }
         int nCl() const { return static_cast<int>(cl_dv.size()); }
 

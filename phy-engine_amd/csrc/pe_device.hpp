@@ -42,7 +42,7 @@ namespace pe
         int nnzA, dv_len;
         int nR, nC, nL, nVdc, nVac, nIdc, nD, nDrv;
         int nonlinear;
-        int nTs, nCl;  // time sources (IAC, generators), coupled-inductor pairs
+        int nTs, nCl, nN3;  // time sources (IAC, generators), coupled-inductor pairs, three-pin non-linear devices (MOSFET, BJT)
         // ---- dv block offsets
         int dv_r, dv_cg, dv_ci, dv_lr, dv_lu, dv_vdc, dv_vac, dv_idc, dv_dg, dv_di, dv_drv;
         // ---- topology (shared by all instances); rows are MNA row indices, -1 = ground
@@ -53,6 +53,7 @@ namespace pe
         int const *ts_kind, *ts_dv;   // time source i: 0 = IAC, 1.. = generator type + 1; dv slot of its value
         int const *cl_n, *cl_k;       // coupled inductors i: rows of p1,p2,s1,s2 [.][4]; absolute rows of the two branches [.][2]
         int const* cl_dv;             // first of its five dv slots: req11, req12, req22, Ueq1, Ueq2
+        int const *n3_kind, *n3_n, *n3_dv;  // MOSFET / BJT i: pe_hip_kind; rows of its pins [.][3]; first dv slot (MOS: gds, gm, Ieq; BJT: geq, Ieq_be, gm, Ieq_c)
         // ---- stamping: CSR of contributions per A slot / per RHS row; entry = (dv index << 1) | negate
         int const *a_ptr, *a_src;
         int const *b_ptr, *b_src;
@@ -63,6 +64,7 @@ namespace pe
         double const* d_par;    // [.][nD][DP_NCOL]
         double const* ts_par;   // [.][nTs][8]  IAC: Ip, omega, phase; generator: type, Vh, Vl, freq, duty, phase, tr, tf
         double const* cl_par;   // [.][nCl][3]  L1, L2, k
+        double const* n3_par;   // [.][nN3][3]  MOS: Kp, lambda, Vth; BJT: Is*Area, N*Ut, BetaF
         // ---- per-instance state
         double *c_hist, *c_prevg;          // [.][nC]
         double *d_udlast, *d_geq, *d_hist, *d_prevg;  // [.][nD]

@@ -106,6 +106,27 @@ namespace
                 out = add_model(nl, g);
                 return true;
             }
+            case 50:
+            case 51:
+            {
+                // BJT{Is, N, BetaF, Temp, Area}
+                double v[5];
+                for(double& q: v) q = take();
+                if(code == 50) out = add_model(nl, BJT_NPN{.Is = v[0], .N = v[1], .BetaF = v[2], .Temp = v[3], .Area = v[4]});
+                else
+                    out = add_model(nl, BJT_PNP{.Is = v[0], .N = v[1], .BetaF = v[2], .Temp = v[3], .Area = v[4]});
+                return true;
+            }
+            case 52:
+            case 53:
+            {
+                // level-1 MOSFET{Kp, lambda, Vth}
+                double const kp = take(), lam = take(), vth = take();
+                if(code == 52) out = add_model(nl, nmosfet{.Kp = kp, .lambda = lam, .Vth = vth});
+                else
+                    out = add_model(nl, pmosfet{.Kp = kp, .lambda = lam, .Vth = vth});
+                return true;
+            }
             default: return false;
         }
     }

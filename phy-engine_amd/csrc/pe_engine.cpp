@@ -123,6 +123,14 @@ namespace
         return code;
     }
 
+    // multi-workgroup schedule (one launch per phase and tree level) instead of the single resident kernel
+    bool split_launch(pe_hip_engine const* h)
+    {
+        if(h->V.n_parts > 1) return true;
+        char const* v = std::getenv("PHY_ENGINE_HIP_SPLIT");  // knob: the per-phase kernels also with one part per instance
+        return v && *v == '1';
+    }
+
     double r_open_of(pe_hip_engine const* h) { return h->opt.r_open > 0.0 ? h->opt.r_open : 1e12; }  // circuit.h:1012
 
     void apply_options(pe_hip_engine* h, pe::DevView& V)
@@ -667,6 +675,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     V.nDrv = hc.n_drives;
     V.nTs = hc.nTs();
     V.nCl = hc.nCl();
+    V.nN3 = hc.nN3();
     V.nonlinear = hc.nonlinear ? 1 : 0;
     V.dv_r = hc.dv_r; V.dv_cg = hc.dv_cg; V.dv_ci = hc.dv_ci; V.dv_lr = hc.dv_lr; V.dv_lu = hc.dv_lu; V.dv_vdc = hc.dv_vdc;
     V.dv_vac = hc.dv_vac; V.dv_idc = hc.dv_idc; V.dv_dg = hc.dv_dg; V.dv_di = hc.dv_di; V.dv_drv = hc.dv_drv;
@@ -694,6 +703,10 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     HIPCHK(h, P.upload(V.cl_k, hc.cl_k));
     HIPCHK(h, P.upload(V.cl_dv, hc.cl_dv));
     HIPCHK(h, P.upload(V.cl_par, hc.cl_par));
+    HIPCHK(h, P.upload(V.n3_kind, hc.n3_kind));
+    HIPCHK(h, P.upload(V.n3_n, hc.n3_n));
+    HIPCHK(h, P.upload(V.n3_dv, hc.n3_dv));
+    HIPCHK(h, P.upload(V.n3_par, hc.n3_par));
     size_t const B = static_cast<size_t>(hc.batch);
     HIPCHK(h, P.alloc(V.c_hist, B * hc.nC()));
     HIPCHK(h, P.alloc(V.c_prevg, B * hc.nC()));
@@ -827,7 +840,7 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     int launches = 0;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     int done = 0;
-    if(h->V.n_parts > 1)
+    if(split_launch(h))
     {
         rc = run_m2_tr(h, dt, nsteps, launches);
         if(rc != PE_HIP_OK) return rc;
@@ -874,7 +887,7 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     if(rc != PE_HIP_OK) return rc;
     h->fact_valid = false;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    if(h->V.n_parts > 1)
+    if(split_launch(h))
     {
         int launches = 0;
         rc = run_m2_dc(h, mode, launches);
@@ -997,6 +1010,14 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
         {
             for(int b = 0; b < B; ++b) col[b] = val(b);
             HIPCHK(h, put_strided(const_cast<double*>(h->V.cl_par) + static_cast<size_t>(d.aux) * 3 + column, static_cast<size_t>(hc.nCl()) * 3, col));
+        }
+        else if(kind >= PE_HIP_NMOS)
+        {
+            for(int c = 0; c < 3; ++c)  // derived columns (a BJT's Is*Area and N*Ut depend on several raw parameters)
+            {
+                for(int b = 0; b < B; ++b) col[b] = hc.n3_par[(static_cast<size_t>(b) * hc.nN3() + d.aux) * 3 + c];
+                HIPCHK(h, put_strided(const_cast<double*>(h->V.n3_par) + static_cast<size_t>(d.aux) * 3 + c, static_cast<size_t>(hc.nN3()) * 3, col));
+            }
         }
         else
         {

@@ -264,6 +264,61 @@ namespace pe
             }
         }
         {
+            // three-pin non-linear devices, re-linearised around the current iterate
+            double const* par = V.n3_par + static_cast<long long>(b) * V.nN3 * 3;
+            for(int i = tm.tid(); i < V.nN3; i += tm.size())
+            {
+                double const* p = par + 3 * i;
+                int const kind = V.n3_kind[i], o = V.n3_dv[i];
+                double const v0 = volt(x, V.n3_n[3 * i]), v1 = volt(x, V.n3_n[3 * i + 1]), v2 = volt(x, V.n3_n[3 * i + 2]);
+                if(kind == 18 || kind == 19)
+                {
+                    // Shichman-Hodges level 1, pins D, G, S: nmosfet.h:91-122, pmosfet.h:91-120
+                    double const Kp = p[0], lambda = p[1], Vth = p[2];
+                    bool const nmos = kind == 18;
+                    double const Vc = nmos ? v1 - v2 : v2 - v1;   // Vgs | Vsg
+                    double const Vds = v0 - v2;
+                    double const Vx = nmos ? Vds : -Vds;          // Vds | Vsd
+                    double const Vov = Vc - Vth;
+                    double Id = 0.0, gm = 0.0, gds = 0.0;
+                    if(Vov <= 0.0) {}
+                    else if(Vx < Vov)
+                    {
+                        double const B = Vov * Vx - 0.5 * Vx * Vx;
+                        double const Ids = Kp * B * (1.0 + lambda * Vx);
+                        double const dI = Kp * ((Vov - Vx) * (1.0 + lambda * Vx) + B * lambda);
+                        Id = nmos ? Ids : -Ids;
+                        gm = Kp * Vx * (1.0 + lambda * Vx);
+                        gds = nmos ? dI : -dI;
+                    }
+                    else
+                    {
+                        double const Ids = 0.5 * Kp * Vov * Vov * (1.0 + lambda * Vx);
+                        Id = nmos ? Ids : -Ids;
+                        gm = Kp * Vov * (1.0 + lambda * Vx);
+                        gds = nmos ? 0.5 * Kp * Vov * Vov * lambda : 0.5 * Kp * Vov * Vov * (-lambda);
+                    }
+                    dv[o] = gds;
+                    dv[o + 1] = gm;
+                    dv[o + 2] = Id - gm * Vc - gds * Vds;
+                }
+                else
+                {
+                    // forward-active Ebers-Moll, pins B, C, E: BJT_NPN.h:122-146, BJT_PNP.h:122-146 (plain exp, no limiting)
+                    double const Is_eff = p[0], Ute = p[1], BetaF = p[2];
+                    double const Vj = kind == 20 ? v0 - v2 : v2 - v0;   // Vbe | Veb
+                    double const e = exp(Vj / Ute);
+                    double const geq = Is_eff * e / Ute;
+                    double const Ij = Is_eff * (e - 1.0);
+                    double const gm = BetaF * geq;
+                    dv[o] = geq;
+                    dv[o + 1] = Ij - Vj * geq;
+                    dv[o + 2] = gm;
+                    dv[o + 3] = BetaF * Ij - gm * Vj;
+                }
+            }
+        }
+        {
             double* udl = V.d_udlast + static_cast<long long>(b) * V.nD;
             double* geqs = V.d_geq + static_cast<long long>(b) * V.nD;
             double const* hist = V.d_hist + static_cast<long long>(b) * V.nD;

@@ -26,6 +26,10 @@ numbering exactly as the reference's `circult::prepare()` does, circuits/circuit
     PULSE p m Vh Vl freq duty phase tr tf   # generator/pulse.h             (1 branch)
     TRI  p m  Vh Vl freq phase      # generator/triangle.h                  (1 branch)
     KL   p1 p2 s1 s2  L1 L2 k       # linear/coupled_inductors.h            (2 branches)
+    NMOS d g s  Kp lambda Vth       # non-linear/nmosfet.h   (level 1)
+    PMOS d g s  Kp lambda Vth       # non-linear/pmosfet.h
+    NPN  b c e  Is N BetaF Temp Area   # non-linear/BJT_NPN.h
+    PNP  b c e  Is N BetaF Temp Area   # non-linear/BJT_PNP.h
 
 Node id -1 = unconnected pin.  Values are printed with %.17g so every consumer reads the same doubles.
 """
@@ -37,11 +41,11 @@ from dataclasses import dataclass, field
 import numpy as np
 
 KINDS = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "FBR", "IAC", "VCCS", "VCVS", "CCCS", "CCVS", "OPAMP", "XFMR", "SW", "SAW", "SQR", "PULSE",
-         "TRI", "KL")
+         "TRI", "KL", "NMOS", "PMOS", "NPN", "PNP")
 NPINS = {"R": 2, "C": 2, "L": 2, "VDC": 2, "VAC": 2, "IDC": 2, "D": 2, "FBR": 4, "IAC": 2, "VCCS": 4, "VCVS": 4, "CCCS": 4, "CCVS": 4,
-         "OPAMP": 4, "XFMR": 4, "SW": 2, "SAW": 2, "SQR": 2, "PULSE": 2, "TRI": 2, "KL": 4}
+         "OPAMP": 4, "XFMR": 4, "SW": 2, "SAW": 2, "SQR": 2, "PULSE": 2, "TRI": 2, "KL": 4, "NMOS": 3, "PMOS": 3, "NPN": 3, "PNP": 3}
 NBRANCH = {"R": 0, "C": 0, "L": 1, "VDC": 1, "VAC": 1, "IDC": 0, "D": 0, "FBR": 0, "IAC": 0, "VCCS": 0, "VCVS": 1, "CCCS": 1, "CCVS": 2,
-           "OPAMP": 1, "XFMR": 2, "SW": 1, "SAW": 1, "SQR": 1, "PULSE": 1, "TRI": 1, "KL": 2}
+           "OPAMP": 1, "XFMR": 2, "SW": 1, "SAW": 1, "SQR": 1, "PULSE": 1, "TRI": 1, "KL": 2, "NMOS": 0, "PMOS": 0, "NPN": 0, "PNP": 0}
 # defaults follow the reference structs' member initialisers
 DEFAULTS = {
     "R": (10.0,),
@@ -61,6 +65,8 @@ DEFAULTS = {
     "PULSE": (5.0, 0.0, 1e3, 0.5, 0.0, 0.0, 0.0),
     "TRI": (5.0, 0.0, 1e3, 0.0),
     "KL": (1e-3, 1e-3, 0.99),
+    "NMOS": (1e-3, 0.0, 1.0), "PMOS": (1e-3, 0.0, 1.0),                   # nmosfet.h:19-21
+    "NPN": (1e-16, 1.0, 100.0, 27.0, 1.0), "PNP": (1e-16, 1.0, 100.0, 27.0, 1.0),   # BJT_NPN.h:15-19
 }
 # generators -> (type code of PE_HIP_VGEN, positions of Vh Vl freq duty phase tr tf in the deck's parameter tuple, -1 = absent)
 VGEN_LAYOUT = {"SAW": (0, (0, 1, 2, -1, 3, -1, -1)), "SQR": (1, (0, 1, 2, 3, 4, -1, -1)), "PULSE": (2, (0, 1, 2, 3, 4, 5, 6)),
@@ -96,7 +102,7 @@ class Deck:
         return sum(1 for k, _, _ in self.devices if k == kind)
 
     def has_nonlinear(self) -> bool:
-        return any(k in ("D", "FBR") for k, _, _ in self.devices)
+        return any(k in ("D", "FBR", "NMOS", "PMOS", "NPN", "PNP") for k, _, _ in self.devices)
 
     def dumps(self) -> str:
         out = [f"nodes {self.n_nodes}"]
@@ -484,4 +490,55 @@ def controlled_mix() -> Deck:
     d.add("SW", (9, 10), 0.0)
     d.add("R", (10, 0), 1e4)
     d.add("L", (8, 0), 1e-3)
+    return d
+
+
+def nmos_common_source(vg: float = 2.0) -> Deck:
+    """NMOS (Kp 2 mA/V^2, lambda 0.02, Vth 1) with a 2 kOhm drain resistor from 5 V, gate at vg: cutoff / saturation / triode by vg."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 5.0)
+    d.add("VDC", (2, 0), vg)
+    d.add("R", (1, 3), 2000.0)
+    d.add("NMOS", (3, 2, 0), 2e-3, 0.02, 1.0)
+    return d
+
+
+def cmos_inverter_tr() -> Deck:
+    """CMOS inverter (PMOS to 3.3 V, NMOS to ground) driven by a 100 kHz pulse with 1 us edges into 1 nF || 10 kOhm."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 3.3)
+    d.add("PULSE", (2, 0), 3.3, 0.0, 1e5, 0.5, 0.0, 1e-6, 1e-6)
+    d.add("PMOS", (3, 2, 1), 1e-3, 0.05, 0.8)
+    d.add("NMOS", (3, 2, 0), 2e-3, 0.05, 0.7)
+    d.add("C", (3, 0), 1e-9)
+    d.add("R", (3, 0), 1e4)
+    return d
+
+
+def bjt_common_emitter(pnp: bool = False) -> Deck:
+    """NPN (or the mirrored PNP) common-emitter stage: 100 kOhm base resistor, 1 kOhm collector resistor, 5 V rail."""
+    d = Deck()
+    d.n_nodes = 3
+    s = -1.0 if pnp else 1.0
+    d.add("VDC", (1, 0), 5.0 * s)
+    d.add("R", (1, 2), 1e5)
+    d.add("R", (1, 3), 1e3)
+    d.add("PNP" if pnp else "NPN", (2, 3, 0), 1e-16, 1.0, 100.0, 27.0, 1.0)
+    return d
+
+
+def bjt_amp_tr() -> Deck:
+    """AC-coupled NPN amplifier: VAC 10 mV / 10 kHz through 1 uF into the biased base, transient."""
+    d = Deck()
+    d.n_nodes = 5
+    d.add("VDC", (1, 0), 9.0)
+    d.add("R", (1, 2), 4.7e5)
+    d.add("R", (1, 3), 2.2e3)
+    d.add("NPN", (2, 3, 0), 1e-15, 1.0, 150.0, 27.0, 1.0)
+    d.add("VAC", (4, 0), 0.01, 2.0 * math.pi * 1e4, 0.0)
+    d.add("C", (4, 2), 1e-6)
+    d.add("C", (3, 5), 1e-7)
+    d.add("R", (5, 0), 1e4)
     return d

@@ -1,7 +1,7 @@
 // models_builtin.h -- the device models of the resident path, with the reference's struct / member names so that
 // netlist-building code is source compatible, and the additive gpu_table_define hook instead of host stamping.
 //   resistance / capacitor / inductor / VDC / VAC / IDC      model/models/linear/*.h
-//   PN_junction / full_bridge_rectifier                      model/models/non-linear/*.h
+//   PN_junction / full_bridge_rectifier / nmosfet / pmosfet / BJT_NPN / BJT_PNP   model/models/non-linear/*.h
 //   IAC / VCCS / VCVS / CCCS / CCVS / op_amp / transformer / coupled_inductors   model/models/linear/*.h
 //   single_pole_switch                                       model/models/controller/switch.h
 //   sawtooth_gen / square_gen / pulse_gen / triangle_gen     model/models/generator/*.h
@@ -593,4 +593,141 @@ namespace phy_engine::model
                  PE_L(3.0, m.Vh, m.Vl, m.freq, 0.5, m.phase, 0.0, 0.0))
 #undef PE_L
 #undef PE_GENERATOR
+
+    // =================================================================== three-pin non-linear devices (re-linearised on the device)
+    // Shichman-Hodges level 1 (non-linear/nmosfet.h, pmosfet.h), forward-active Ebers-Moll (non-linear/BJT_NPN.h, BJT_PNP.h)
+    struct nmosfet
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"NMOSFET"};
+        inline static constexpr model_device_type device_type{model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"NMOS"};
+        double Kp{1e-3};     // A/V^2
+        double lambda{0.0};  // 1/V
+        double Vth{1.0};     // V
+        pin pins[3]{{{u8"D"}}, {{u8"G"}}, {{u8"S"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<nmosfet>, nmosfet& m, ::std::size_t n, variant vi) noexcept
+    {
+        double nmosfet::* const f[3] = {&nmosfet::Kp, &nmosfet::lambda, &nmosfet::Vth};
+        return n < 3 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<nmosfet>, nmosfet const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.Kp) : n == 1 ? details::dvar(m.lambda) : n == 2 ? details::dvar(m.Vth) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<nmosfet>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[3] = {u8"Kp", u8"lambda", u8"Vth"};
+        return n < 3 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<nmosfet>, nmosfet& m) noexcept { return {m.pins, 3}; }
+    inline bool gpu_table_define(model_reserve_type_t<nmosfet>, nmosfet const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_NMOS, 0, 1, -1, {m.Kp, m.lambda, m.Vth}, 2, -1, -1};
+        return true;
+    }
+
+    struct pmosfet
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"PMOSFET"};
+        inline static constexpr model_device_type device_type{model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"PMOS"};
+        double Kp{1e-3};     // A/V^2
+        double lambda{0.0};  // 1/V
+        double Vth{1.0};     // V
+        pin pins[3]{{{u8"D"}}, {{u8"G"}}, {{u8"S"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<pmosfet>, pmosfet& m, ::std::size_t n, variant vi) noexcept
+    {
+        double pmosfet::* const f[3] = {&pmosfet::Kp, &pmosfet::lambda, &pmosfet::Vth};
+        return n < 3 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<pmosfet>, pmosfet const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.Kp) : n == 1 ? details::dvar(m.lambda) : n == 2 ? details::dvar(m.Vth) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<pmosfet>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[3] = {u8"Kp", u8"lambda", u8"Vth"};
+        return n < 3 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<pmosfet>, pmosfet& m) noexcept { return {m.pins, 3}; }
+    inline bool gpu_table_define(model_reserve_type_t<pmosfet>, pmosfet const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_PMOS, 0, 1, -1, {m.Kp, m.lambda, m.Vth}, 2, -1, -1};
+        return true;
+    }
+
+    struct BJT_NPN
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"NPN BJT"};
+        inline static constexpr model_device_type device_type{model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"QNP"};
+        double Is{1e-16};
+        double N{1.0};
+        double BetaF{100.0};
+        double Temp{27.0};
+        double Area{1.0};
+        pin pins[3]{{{u8"B"}}, {{u8"C"}}, {{u8"E"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<BJT_NPN>, BJT_NPN& m, ::std::size_t n, variant vi) noexcept
+    {
+        double BJT_NPN::* const f[5] = {&BJT_NPN::Is, &BJT_NPN::N, &BJT_NPN::BetaF, &BJT_NPN::Temp, &BJT_NPN::Area};
+        return n < 5 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<BJT_NPN>, BJT_NPN const& m, ::std::size_t n) noexcept
+    {
+        double BJT_NPN::* const f[5] = {&BJT_NPN::Is, &BJT_NPN::N, &BJT_NPN::BetaF, &BJT_NPN::Temp, &BJT_NPN::Area};
+        return n < 5 ? details::dvar(m.*f[n]) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<BJT_NPN>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[5] = {u8"Is", u8"N", u8"BetaF", u8"Temp", u8"Area"};
+        return n < 5 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<BJT_NPN>, BJT_NPN& m) noexcept { return {m.pins, 3}; }
+    inline bool gpu_table_define(model_reserve_type_t<BJT_NPN>, BJT_NPN const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_BJT_NPN, 0, 1, -1, {m.Is, m.N, m.BetaF, m.Temp, m.Area}, 2, -1, -1};
+        return true;
+    }
+
+    struct BJT_PNP
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"PNP BJT"};
+        inline static constexpr model_device_type device_type{model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"QPN"};
+        double Is{1e-16};
+        double N{1.0};
+        double BetaF{100.0};
+        double Temp{27.0};
+        double Area{1.0};
+        pin pins[3]{{{u8"B"}}, {{u8"C"}}, {{u8"E"}}};
+    };
+    inline bool set_attribute_define(model_reserve_type_t<BJT_PNP>, BJT_PNP& m, ::std::size_t n, variant vi) noexcept
+    {
+        double BJT_PNP::* const f[5] = {&BJT_PNP::Is, &BJT_PNP::N, &BJT_PNP::BetaF, &BJT_PNP::Temp, &BJT_PNP::Area};
+        return n < 5 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<BJT_PNP>, BJT_PNP const& m, ::std::size_t n) noexcept
+    {
+        double BJT_PNP::* const f[5] = {&BJT_PNP::Is, &BJT_PNP::N, &BJT_PNP::BetaF, &BJT_PNP::Temp, &BJT_PNP::Area};
+        return n < 5 ? details::dvar(m.*f[n]) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<BJT_PNP>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[5] = {u8"Is", u8"N", u8"BetaF", u8"Temp", u8"Area"};
+        return n < 5 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<BJT_PNP>, BJT_PNP& m) noexcept { return {m.pins, 3}; }
+    inline bool gpu_table_define(model_reserve_type_t<BJT_PNP>, BJT_PNP const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_BJT_PNP, 0, 1, -1, {m.Is, m.N, m.BetaF, m.Temp, m.Area}, 2, -1, -1};
+        return true;
+    }
+
 }  // namespace phy_engine::model

@@ -287,7 +287,7 @@ namespace phy_engine
             int branch2{-1};          // second branch row of the two-branch kinds
         };
         // node / branch / parameter columns per device of a pe_hip_kind (pe_hip.h)
-        inline constexpr int gpu_kind_pins(int k) noexcept { return (k <= PE_HIP_IAC || k == PE_HIP_SWITCH || k == PE_HIP_VGEN) ? 2 : 4; }
+        inline constexpr int gpu_kind_pins(int k) noexcept { return k >= PE_HIP_NMOS ? 3 : ((k <= PE_HIP_IAC || k == PE_HIP_SWITCH || k == PE_HIP_VGEN) ? 2 : 4); }
         inline constexpr int gpu_kind_branches(int k) noexcept
         {
             switch(k)
@@ -312,7 +312,11 @@ namespace phy_engine
             {
                 case PE_HIP_VAC:
                 case PE_HIP_IAC:
-                case PE_HIP_COUPLED_L: return 3;
+                case PE_HIP_COUPLED_L:
+                case PE_HIP_NMOS:
+                case PE_HIP_PMOS: return 3;
+                case PE_HIP_BJT_NPN:
+                case PE_HIP_BJT_PNP: return 5;
                 case PE_HIP_DIODE: return PE_HIP_DIODE_NPARAM;
                 case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
                 default: return 1;
@@ -926,11 +930,8 @@ namespace phy_engine
                         auto& t = next.kind[row.kind];
                         t.nodes.push_back(node_id(row.pin_a));
                         t.nodes.push_back(node_id(row.pin_b));
-                        if(model::gpu_kind_pins(row.kind) == 4)
-                        {
-                            t.nodes.push_back(node_id(row.pin_c));
-                            t.nodes.push_back(node_id(row.pin_d));
-                        }
+                        if(model::gpu_kind_pins(row.kind) >= 3) t.nodes.push_back(node_id(row.pin_c));
+                        if(model::gpu_kind_pins(row.kind) == 4) t.nodes.push_back(node_id(row.pin_d));
                         if(row.branch >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch);
                         if(row.branch2 >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch2);
                         int const ncol = model::gpu_kind_ncol(row.kind);

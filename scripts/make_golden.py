@@ -69,6 +69,17 @@ CASES["coupled_l_dc"] = (("coupled_inductors_tr", {"k": 0.5}), "DC", 0.0, 0, 0.0
 CASES["controlled_mix_tr"] = (("controlled_mix", {}), "TR", 1e-6, 300, 0.0, "1,10,100,300", True)
 
 
+# three-pin non-linear devices (no dedicated test in the reference besides the loader coverage: circuits are ours)
+CASES["nmos_cutoff_dc"] = (("nmos_common_source", {"vg": 0.5}), "DC", 0.0, 0, 0.0, "", True)
+CASES["nmos_sat_dc"] = (("nmos_common_source", {"vg": 2.0}), "DC", 0.0, 0, 0.0, "", True)
+CASES["nmos_triode_op"] = (("nmos_common_source", {"vg": 4.5}), "OP", 0.0, 0, 0.0, "", True)
+CASES["cmos_inverter_tr"] = (("cmos_inverter_tr", {}), "TR", 1e-7, 250, 1e-12, "1,3,10,50,55,100,105,250", True)
+CASES["bjt_npn_ce_dc_fail"] = (("bjt_common_emitter", {"pnp": False}), "DC", 0.0, 0, 0.0, "", True)
+CASES["bjt_pnp_ce_op_fail"] = (("bjt_common_emitter", {"pnp": True}), "OP", 0.0, 0, 0.0, "", True)
+CASES["bjt_amp_tr"] = (("bjt_amp_tr", {}), "TR", 1e-6, 300, 0.0, "1,10,100,300", True)
+CASES["bjt_amp_trop_fail"] = (("bjt_amp_tr", {}), "TROP", 1e-6, 50, 0.0, "0,1,50", True)   # cold-start OP of an unlimited exp: the reference gives up
+
+
 def tt_diode_deck():
     """test/0004.solver/pn_junction_tt_tr.cpp: VDC 0.7 + VAC 0.1 (omega*dt = pi/2) across a tt=1e-9 diode."""
     import math

@@ -53,6 +53,46 @@ def test_stamper_golden_parity(eng, name, tol):
     assert list(trace) == meta["newton_iters"]
 
 
+@pytest.mark.parametrize("name", ["nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr"])
+def test_three_pin_nonlinear_golden_parity(eng, name):
+    """Level-1 MOSFETs and the forward-active BJT (device kinds 18-21): same Newton trajectory as the reference."""
+    meta, gx, deck = golden(name)
+    snaps, trace, fail = run_engine_case(eng, meta, deck)
+    assert fail == -1 and meta["fail_step"] == -1
+    assert len(snaps) == len(gx)
+    assert max_err(snaps[:, 0, :], gx, *NL) <= 1.0
+    assert list(trace) == meta["newton_iters"]
+
+
+@pytest.mark.parametrize("name", ["bjt_npn_ce_dc_fail", "bjt_pnp_ce_op_fail", "bjt_amp_trop_fail"])
+def test_unlimited_exponential_fails_like_reference(eng, name):
+    """The reference's BJT exponential has no junction limiting: a cold-start operating point overflows and the reference
+    reports failure (64 Newton iterations).  The engine must fail too (non-finite iterate or no convergence), not invent an answer."""
+    meta, gx, deck = golden(name)
+    assert meta["fail_step"] == 0
+    snaps, trace, fail = run_engine_case(eng, meta, deck)
+    assert fail == 0
+    assert eng.state()["status"][0] in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_NO_CONVERGENCE)
+
+
+def test_mosfet_param_update(eng):
+    """update_param on a resident MOSFET (Vth) and BJT (Temp -> N*Ut derived on the host) re-solves with the new values."""
+    d = pe.deck.nmos_common_source(2.0)
+    eng.set_options(g_min=0.0)
+    eng.load_deck(d)
+    eng.reset()
+    eng.analyze_dc(pe.ffi.MODE_DC)
+    v_a = eng.solution()[0][2]
+    eng.update_param(pe.ffi.NMOS, 0, 2, [1.5])      # Vth 1.0 -> 1.5: less current, higher drain voltage
+    eng.analyze_dc(pe.ffi.MODE_DC)
+    v_b = eng.solution()[0][2]
+    Kp, lam = 2e-3, 0.02
+    # saturation: (5 - vd) / 2000 = 0.5 Kp Vov^2 (1 + lam vd)
+    for v, vov in ((v_a, 1.0), (v_b, 0.5)):
+        assert abs((5.0 - v) / 2000.0 - 0.5 * Kp * vov * vov * (1.0 + lam * v)) < 1e-9
+    assert v_b > v_a
+
+
 def test_switch_toggle_and_param_updates(eng):
     """test/0005.models/cutthrough.cpp idea: the same resident circuit, switch opened / closed through update_param;
     a controlled source's gain and a generator's level changed the same way."""

@@ -12,7 +12,8 @@ FAST = ["rc_step", "rl_step", "rlc_series_vl", "rlc_series_vl_trop", "divider_dc
 # the remaining linear stampers (goldens from the reference's own model tests + transient variants)
 STAMPERS = ["vccs_dc", "vcvs_gain", "cccs_dc", "ccvs_dc", "op_amp_follower", "transformer_ratio", "generator_dc", "switch_open_dc",
             "switch_closed_dc", "switch_open_ropen1e6_dc", "generators_tr", "generators_trop", "iac_rc_tr", "iac_rc_dc", "iac_rc_trop",
-            "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop", "coupled_l_dc", "controlled_mix_tr"]
+            "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop", "coupled_l_dc", "controlled_mix_tr",
+            "nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr"]
 
 
 def run_oracle(orc, meta, deck):
@@ -32,6 +33,22 @@ def test_oracle_matches_reference_golden(oracle_mod, name):
     # fp64, same algorithm family (SuperLU vs Eigen's SuperLU port): 1e-9 abs + 1e-9 rel
     assert np.all(np.abs(xs - gx) <= 1e-9 + 1e-9 * np.abs(gx))
     assert o.newton_iters == meta["newton_iters"]
+
+
+@pytest.mark.parametrize("name", ["bjt_npn_ce_dc_fail", "bjt_pnp_ce_op_fail", "bjt_amp_trop_fail"])
+def test_oracle_unlimited_exponential_fails_like_reference(oracle_mod, name):
+    """The reference's BJT has a plain exp without junction limiting (BJT_NPN.h:128): a cold-start operating point
+    overflows and Newton gives up after 64 iterations.  Same behaviour required, not a 'better' answer."""
+    meta, gx, deck = golden(name)
+    assert meta["fail_step"] == 0 and meta["newton_iters"] == [-2]
+    o = oracle_mod.Oracle(deck, g_min=meta["gmin"])
+    with np.errstate(all="ignore"):
+        if meta["analysis"] == "TROP":
+            o.analyze_tr(meta["dt"], meta["steps"], set(), trop=True)
+            assert o.fail_step == 0
+        else:
+            assert not o.analyze_dc(meta["analysis"])
+    assert o.newton_iters[0] < 0
 
 
 def test_oracle_mesh100_first_steps(oracle_mod):
