@@ -72,11 +72,15 @@ enum pe_hip_kind
     PE_HIP_NMOS = 18,     /* nodes D,G,S  params: Kp, lambda, Vth   Shichman-Hodges level 1 (non-linear/nmosfet.h:84-141) */
     PE_HIP_PMOS = 19,     /* nodes D,G,S  params: Kp, lambda, Vth                          (non-linear/pmosfet.h:84-139) */
     PE_HIP_BJT_NPN = 20,  /* nodes B,C,E  params: Is, N, BetaF, Temp, Area   forward-active Ebers-Moll (non-linear/BJT_NPN.h:100-158) */
-    PE_HIP_BJT_PNP = 21   /* nodes B,C,E  params: Is, N, BetaF, Temp, Area                  (non-linear/BJT_PNP.h:100-158) */
+    PE_HIP_BJT_PNP = 21,  /* nodes B,C,E  params: Is, N, BetaF, Temp, Area                  (non-linear/BJT_PNP.h:100-158) */
+    PE_HIP_RELAY = 22,    /* nodes C+,C-,A,B +1 br  params: Von, Voff   contact A-B closes at v(C+)-v(C-) >= Von, opens at <= Voff (state
+                             per instance, re-evaluated at every stamp; open = r_open); counts as non-linear (controller/relay.h:75-105) */
+    PE_HIP_XFMR_CT = 23   /* nodes P,Q,S1,CT,S2 [count][5] +3 br (kP, kH1, kH2)  params: n_total = Vp / V(S1-S2)
+                                                                                   (linear/transformer_center_tap.h:71-132) */
 };
 #define PE_HIP_DIODE_NPARAM 11
 #define PE_HIP_VGEN_NPARAM 8
-#define PE_HIP_KIND_MAX 21
+#define PE_HIP_KIND_MAX 23
 
 /* analysis modes (phy_engine::analyze_type, circuits/analyze.h:7-16) */
 enum pe_hip_mode
@@ -91,7 +95,7 @@ typedef struct pe_hip_device_table
 {
     int kind;             /* pe_hip_kind */
     int count;            /* devices in this table */
-    const int* nodes;     /* [count][pins] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin (pins = 2, 3 or 4: see pe_hip_kind) */
+    const int* nodes;     /* [count][pins] node ids: 0 = ground, 1..n_nodes, -1 = unconnected pin (pins = 2 .. 5: see pe_hip_kind) */
     const int* branch;    /* [count][branches] global branch index (0-based, after digital drives) for kinds with branch rows, else NULL */
     const double* params; /* [batch][count][ncol] when params_batched, else [count][ncol] (shared by every instance) */
     int params_batched;

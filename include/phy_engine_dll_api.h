@@ -5,10 +5,10 @@
  * Subset (SURVEY.md 8b "FFI loader"): element codes 1 R, 2 C, 3 L, 4 VDC, 5 VAC{Vp, f[Hz], phase[deg]}, 6 IDC,
  * 13 PN_junction{Is,N,Isr,Nr,Temp,Ibv,Bv,Bv_set,Area}, 54 full_bridge_rectifier, 0 = ground placeholder, and (SURVEY.md 8f
  * rank 1) 7 IAC{Ip, f[Hz], phase[deg]}, 8 VCCS{G}, 9 VCVS{Mu}, 10 CCCS{alpha}, 11 CCVS{r}, 12 switch{cut_through},
- * 14 transformer{n}, 15 coupled inductors{L1,L2,k}, 17 op-amp{mu}, 20 sawtooth{Vh,Vl,f,phase}, 21 square{Vh,Vl,f,duty,phase},
+ * 14 transformer{n}, 15 coupled inductors{L1,L2,k}, 16 center-tap transformer{n_total}, 17 op-amp{mu}, 18 relay{Von,Voff}, 20 sawtooth{Vh,Vl,f,phase}, 21 square{Vh,Vl,f,duty,phase},
  * 22 pulse{Vh,Vl,f,duty,phase,tr,tf}, 23 triangle{Vh,Vl,f,phase}, 50/51 BJT NPN/PNP{Is,N,BetaF,Temp,Area},
  * 52/53 level-1 N/PMOSFET{Kp,lambda,Vth}.  Every analysis runs on the MI355X through include/pe_hip.h.  Other element codes
- * (center-tap transformer, relay, BSIM3, digital, Verilog) are rejected.
+ * (BSIM3, the digital gate library beyond the C4 subset, Verilog) are rejected.
  */
 #ifndef PHY_ENGINE_DLL_API_SUBSET_H
 #define PHY_ENGINE_DLL_API_SUBSET_H

@@ -41,6 +41,8 @@
 #include <phy_engine/model/models/linear/transformer.h>
 #include <phy_engine/model/models/linear/coupled_inductors.h>
 #include <phy_engine/model/models/controller/switch.h>
+#include <phy_engine/model/models/controller/relay.h>
+#include <phy_engine/model/models/linear/transformer_center_tap.h>
 #include <phy_engine/model/models/generator/sawtooth.h>
 #include <phy_engine/model/models/generator/square.h>
 #include <phy_engine/model/models/generator/pulse.h>
@@ -70,6 +72,8 @@ struct deck
 
 static int n_pins_of(std::string const& k)
 {
+    if(k == "XCT") return 5;
+    if(k == "RELAY") return 4;
     if(k == "FBR" || k == "VCCS" || k == "VCVS" || k == "CCCS" || k == "CCVS" || k == "OPAMP" || k == "XFMR" || k == "KL") return 4;
     if(k == "NMOS" || k == "PMOS" || k == "NPN" || k == "PNP") return 3;
     return 2;
@@ -159,6 +163,14 @@ static bool build(pe::circult& c, deck const& d)
             m = add_model(nl, pe::model::BJT_NPN{.Is = P(0, 1e-16), .N = P(1, 1.0), .BetaF = P(2, 100.0), .Temp = P(3, 27.0), .Area = P(4, 1.0)}).mod;
         else if(l.kind == "PNP")
             m = add_model(nl, pe::model::BJT_PNP{.Is = P(0, 1e-16), .N = P(1, 1.0), .BetaF = P(2, 100.0), .Temp = P(3, 27.0), .Area = P(4, 1.0)}).mod;
+        else if(l.kind == "RELAY")
+        {
+            pe::model::relay r{};
+            r.Von = P(0, 5.0);
+            r.Voff = P(1, 3.0);
+            m = add_model(nl, std::move(r)).mod;
+        }
+        else if(l.kind == "XCT") m = add_model(nl, pe::model::transformer_center_tap{.n_total = P(0, 1.0)}).mod;
         else if(l.kind == "KL") m = add_model(nl, pe::model::coupled_inductors{.L1 = P(0, 1e-3), .L2 = P(1, 1e-3), .k = P(2, 0.99)}).mod;
         else
         {

@@ -21,6 +21,8 @@ namespace pe
 
     int gen_pins(int kind)
     {
+        if(kind == PE_HIP_XFMR_CT) return 5;
+        if(kind == PE_HIP_RELAY) return 4;
         if(kind >= PE_HIP_NMOS) return 3;
         return (kind == PE_HIP_IAC || kind == PE_HIP_SWITCH || kind == PE_HIP_VGEN) ? 2 : 4;
     }
@@ -37,6 +39,7 @@ namespace pe
             case PE_HIP_CCVS:
             case PE_HIP_XFMR:
             case PE_HIP_COUPLED_L: return 2;
+            case PE_HIP_XFMR_CT: return 3;
             default: return 1;
         }
     }
@@ -50,6 +53,7 @@ namespace pe
             case PE_HIP_PMOS: return 3;
             case PE_HIP_BJT_NPN:
             case PE_HIP_BJT_PNP: return 5;
+            case PE_HIP_RELAY: return 2;
             case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
             default: return 1;
         }
@@ -72,6 +76,7 @@ namespace pe
             case PE_HIP_OPAMP:
             case PE_HIP_XFMR: out = raw[0]; return true;
             case PE_HIP_SWITCH: out = raw[0] != 0.0 ? 0.0 : r_open; return true;  // switch.h:93
+            case PE_HIP_XFMR_CT: out = raw[0] != 0.0 ? 1.0 / (2.0 * raw[0]) : 0.0; return true;  // 1 / n_half, transformer_center_tap.h:73,108
             default: return false;
         }
     }
@@ -93,6 +98,12 @@ namespace pe
         {
             double* o = &hc.cl_par[(static_cast<size_t>(b) * hc.nCl() + d.aux) * 3];
             for(int c = 0; c < 3; ++c) o[c] = raw[c];
+        }
+        else if(d.kind == PE_HIP_RELAY)
+        {
+            double* o = &hc.rl_par[(static_cast<size_t>(b) * hc.nRl() + d.aux) * 2];
+            o[0] = raw[0];
+            o[1] = raw[1];
         }
         else if(d.kind == PE_HIP_NMOS || d.kind == PE_HIP_PMOS)
         {
@@ -200,7 +211,7 @@ namespace pe
                     HostCircuit::GenDev d{};
                     d.kind = t.kind;
                     d.aux = -1;
-                    for(int q = 0; q < 4; ++q) d.n[q] = -1;
+                    for(int q = 0; q < 5; ++q) d.n[q] = -1;
                     for(int q = 0; q < pins; ++q)
                     {
                         int const id = t.nodes[pins * i + q];
@@ -391,6 +402,14 @@ namespace pe
                 hc.ts_kind.push_back(type);
                 hc.ts_dv.push_back(0);
             }
+            else if(d.kind == PE_HIP_RELAY)
+            {
+                d.aux = hc.nRl();
+                hc.rl_n.push_back(d.n[0]);
+                hc.rl_n.push_back(d.n[1]);
+                hc.rl_dv.push_back(0);
+            }
+            else if(d.kind == PE_HIP_XFMR_CT) {}
             else if(d.kind >= PE_HIP_NMOS)
             {
                 d.aux = hc.nN3();
@@ -410,7 +429,8 @@ namespace pe
         hc.ts_par.assign(static_cast<size_t>(batch) * hc.nTs() * 8, 0.0);
         hc.cl_par.assign(static_cast<size_t>(batch) * hc.nCl() * 3, 0.0);
         hc.n3_par.assign(static_cast<size_t>(batch) * hc.nN3() * 3, 0.0);
-        hc.nonlinear = hc.nonlinear || hc.nN3() > 0;
+        hc.rl_par.assign(static_cast<size_t>(batch) * hc.nRl() * 2, 0.0);
+        hc.nonlinear = hc.nonlinear || hc.nN3() > 0 || hc.nRl() > 0;  // relay.h:12: device_type non_linear
         for(size_t g = 0; g < hc.gen.size(); ++g)
             for(int inst = 0; inst < batch; ++inst) gen_derive(hc, static_cast<int>(g), inst);
 
@@ -435,7 +455,9 @@ namespace pe
             if(d.kind == PE_HIP_IAC || d.kind == PE_HIP_VGEN) hc.ts_dv[d.aux] = d.dv;
             else if(d.kind == PE_HIP_COUPLED_L)
                 hc.cl_dv[d.aux] = d.dv;
-            else if(d.kind >= PE_HIP_NMOS)
+            else if(d.kind == PE_HIP_RELAY)
+                hc.rl_dv[d.aux] = d.dv;
+            else if(d.kind >= PE_HIP_NMOS && d.kind <= PE_HIP_BJT_PNP)
                 hc.n3_dv[d.aux] = d.dv;
         }
         hc.dv_len = o;
@@ -622,6 +644,29 @@ namespace pe
                     B_add(n[2], v + 3, true);
                     B_add(n[1], v + 3, false);
                     break;
+                case PE_HIP_RELAY:  // relay.h:97-102 (pins C+, C-, A, B)
+                    incidence(n[2], n[3], k[0]);
+                    A_set(k[0], k[0], v, true);
+                    break;
+                case PE_HIP_XFMR_CT:  // transformer_center_tap.h:96-130 (pins P, Q, S1, CT, S2; branches kP, kH1, kH2); v = 1 / n_half
+                    A_set(n[0], k[0], DV_ONE, false);
+                    A_set(n[1], k[0], DV_ONE, true);
+                    A_set(n[2], k[1], DV_ONE, false);
+                    A_set(n[3], k[1], DV_ONE, true);
+                    A_set(n[3], k[2], DV_ONE, false);
+                    A_set(n[4], k[2], DV_ONE, true);
+                    A_set(k[1], n[2], DV_ONE, false);
+                    A_set(k[1], n[3], DV_ONE, true);
+                    A_add(k[1], n[0], v, true);
+                    A_add(k[1], n[1], v, false);
+                    A_set(k[2], n[3], DV_ONE, false);
+                    A_set(k[2], n[4], DV_ONE, true);
+                    A_add(k[2], n[0], v, true);
+                    A_add(k[2], n[1], v, false);
+                    A_set(k[0], k[0], DV_ONE, false);
+                    A_set(k[0], k[1], v, false);
+                    A_set(k[0], k[2], v, false);
+                    break;
                 case PE_HIP_COUPLED_L:  // coupled_inductors.h:223-243 (zeros in the D / E cells reproduce the DC stamp :104-112)
                     A_set(n[0], k[0], DV_ONE, false);
                     A_set(n[1], k[0], DV_ONE, true);
@@ -707,6 +752,7 @@ namespace pe
             double const* raw = &hc.gen_par[d.par];
             double sv;
             if(gen_static_value(d.kind, raw, r_open, sv)) dv[d.dv] = sv;
+            else if(d.kind == PE_HIP_RELAY) dv[d.dv] = r_open;
             else if(d.kind == PE_HIP_NMOS || d.kind == PE_HIP_PMOS)
             {
                 dv[d.dv] = 1e-2 * raw[0];  // representative gds / gm of a conducting device (|Vov| ~ 10 mV .. 1 V)

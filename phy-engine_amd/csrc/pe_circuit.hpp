@@ -44,8 +44,8 @@ namespace pe
         struct GenDev
         {
             int kind;
-            int n[4];   // MNA rows of the pins (-1 = ground)
-            int k[2];   // absolute rows of its branches
+            int n[5];   // MNA rows of the pins (-1 = ground)
+            int k[3];   // absolute rows of its branches
             int par;    // offset of its raw parameter columns inside one instance's block of gen_par
             int dv;     // first dv slot (gen_ndv(kind) slots)
             int aux;    // index in ts_* (IAC, VGEN) or cl_* (COUPLED_L), else -1
@@ -59,6 +59,9 @@ namespace pe
         std::vector<double> ts_par;    // [batch][nTs][8]
         std::vector<int> cl_n, cl_k, cl_dv;
         std::vector<double> cl_par;    // [batch][nCl][3]
+        std::vector<int> rl_n, rl_dv;
+        std::vector<double> rl_par;    // [batch][nRl][2]
+        int nRl() const { return static_cast<int>(rl_dv.size()); }
         std::vector<int> n3_kind, n3_n, n3_dv;
         std::vector<double> n3_par;    // [batch][nN3][3]
         int nN3() const { return static_cast<int>(n3_kind.size()); }

@@ -42,7 +42,7 @@ namespace pe
         int nnzA, dv_len;
         int nR, nC, nL, nVdc, nVac, nIdc, nD, nDrv;
         int nonlinear;
-        int nTs, nCl, nN3;  // time sources (IAC, generators), coupled-inductor pairs, three-pin non-linear devices (MOSFET, BJT)
+        int nTs, nCl, nN3, nRl;  // time sources (IAC, generators), coupled-inductor pairs, three-pin non-linear devices (MOSFET, BJT), relays
         // ---- dv block offsets
         int dv_r, dv_cg, dv_ci, dv_lr, dv_lu, dv_vdc, dv_vac, dv_idc, dv_dg, dv_di, dv_drv;
         // ---- topology (shared by all instances); rows are MNA row indices, -1 = ground
@@ -65,6 +65,10 @@ namespace pe
         double const* ts_par;   // [.][nTs][8]  IAC: Ip, omega, phase; generator: type, Vh, Vl, freq, duty, phase, tr, tf
         double const* cl_par;   // [.][nCl][3]  L1, L2, k
         double const* n3_par;   // [.][nN3][3]  MOS: Kp, lambda, Vth; BJT: Is*Area, N*Ut, BetaF
+        int const *rl_n, *rl_dv; // relay i: rows of its coil pins [.][2]; dv slot of its contact resistance
+        double const* rl_par;   // [.][nRl][2]  Von, Voff
+        int* rl_engaged;        // [.][nRl]     contact state (relay.h:85-92)
+        double r_open;          // contact resistance of an open relay / switch
         // ---- per-instance state
         double *c_hist, *c_prevg;          // [.][nC]
         double *d_udlast, *d_geq, *d_hist, *d_prevg;  // [.][nD]

@@ -77,7 +77,16 @@ namespace
                 out = add_model(nl, kl);
                 return true;
             }
+            case 16: out = add_model(nl, transformer_center_tap{.n_total = take()}); return true;
             case 17: out = add_model(nl, op_amp{.mu = take()}); return true;
+            case 18:
+            {
+                relay r{};
+                r.Von = take();
+                r.Voff = take();
+                out = add_model(nl, r);
+                return true;
+            }
             case 20:
             {
                 sawtooth_gen g{};

@@ -141,6 +141,7 @@ namespace
         V.i_abstol = o.i_abstol > 0.0 ? o.i_abstol : 1e-12;
         V.i_reltol = o.i_reltol > 0.0 ? o.i_reltol : V.v_reltol;
         V.max_newton = o.max_newton > 0 ? o.max_newton : 64;
+        V.r_open = r_open_of(h);
     }
 
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
@@ -676,6 +677,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     V.nTs = hc.nTs();
     V.nCl = hc.nCl();
     V.nN3 = hc.nN3();
+    V.nRl = hc.nRl();
     V.nonlinear = hc.nonlinear ? 1 : 0;
     V.dv_r = hc.dv_r; V.dv_cg = hc.dv_cg; V.dv_ci = hc.dv_ci; V.dv_lr = hc.dv_lr; V.dv_lu = hc.dv_lu; V.dv_vdc = hc.dv_vdc;
     V.dv_vac = hc.dv_vac; V.dv_idc = hc.dv_idc; V.dv_dg = hc.dv_dg; V.dv_di = hc.dv_di; V.dv_drv = hc.dv_drv;
@@ -707,6 +709,10 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     HIPCHK(h, P.upload(V.n3_n, hc.n3_n));
     HIPCHK(h, P.upload(V.n3_dv, hc.n3_dv));
     HIPCHK(h, P.upload(V.n3_par, hc.n3_par));
+    HIPCHK(h, P.upload(V.rl_n, hc.rl_n));
+    HIPCHK(h, P.upload(V.rl_dv, hc.rl_dv));
+    HIPCHK(h, P.upload(V.rl_par, hc.rl_par));
+    HIPCHK(h, P.alloc(V.rl_engaged, std::max<size_t>(1, static_cast<size_t>(hc.batch) * hc.nRl())));
     size_t const B = static_cast<size_t>(hc.batch);
     HIPCHK(h, P.alloc(V.c_hist, B * hc.nC()));
     HIPCHK(h, P.alloc(V.c_prevg, B * hc.nC()));
@@ -813,6 +819,7 @@ int pe_hip_reset(pe_hip_engine* h)
     HIPCHK(h, hipMemset(V.d_geq, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
     HIPCHK(h, hipMemset(V.d_hist, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
     HIPCHK(h, hipMemset(V.d_prevg, 0, std::max<size_t>(1, B * hc.nD()) * sizeof(double)));
+    HIPCHK(h, hipMemset(V.rl_engaged, 0, std::max<size_t>(1, B * hc.nRl()) * sizeof(int)));
     HIPCHK(h, hipMemset(V.t_now, 0, B * sizeof(double)));
     HIPCHK(h, hipMemset(V.last_step, 0, B * sizeof(double)));
     HIPCHK(h, hipMemset(V.status, 0, B * sizeof(int)));
@@ -1010,6 +1017,11 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
         {
             for(int b = 0; b < B; ++b) col[b] = val(b);
             HIPCHK(h, put_strided(const_cast<double*>(h->V.cl_par) + static_cast<size_t>(d.aux) * 3 + column, static_cast<size_t>(hc.nCl()) * 3, col));
+        }
+        else if(kind == PE_HIP_RELAY)
+        {
+            for(int b = 0; b < B; ++b) col[b] = val(b);
+            HIPCHK(h, put_strided(const_cast<double*>(h->V.rl_par) + static_cast<size_t>(d.aux) * 2 + column, static_cast<size_t>(hc.nRl()) * 2, col));
         }
         else if(kind >= PE_HIP_NMOS)
         {

@@ -264,6 +264,24 @@ namespace pe
             }
         }
         {
+            // relays: the contact follows the coil voltage of the current iterate with hysteresis (relay.h:84-95)
+            double const* par = V.rl_par + static_cast<long long>(b) * V.nRl * 2;
+            int* eng = V.rl_engaged + static_cast<long long>(b) * V.nRl;
+            for(int i = tm.tid(); i < V.nRl; i += tm.size())
+            {
+                double const vctrl = volt(x, V.rl_n[2 * i]) - volt(x, V.rl_n[2 * i + 1]);
+                int e = eng[i];
+                if(!e)
+                {
+                    if(vctrl >= par[2 * i]) e = 1;
+                }
+                else if(vctrl <= par[2 * i + 1])
+                    e = 0;
+                eng[i] = e;
+                dv[V.rl_dv[i]] = e ? 0.0 : V.r_open;
+            }
+        }
+        {
             // three-pin non-linear devices, re-linearised around the current iterate
             double const* par = V.n3_par + static_cast<long long>(b) * V.nN3 * 3;
             for(int i = tm.tid(); i < V.nN3; i += tm.size())

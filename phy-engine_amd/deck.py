@@ -30,6 +30,8 @@ numbering exactly as the reference's `circult::prepare()` does, circuits/circuit
     PMOS d g s  Kp lambda Vth       # non-linear/pmosfet.h
     NPN  b c e  Is N BetaF Temp Area   # non-linear/BJT_NPN.h
     PNP  b c e  Is N BetaF Temp Area   # non-linear/BJT_PNP.h
+    RELAY cp cn a b  Von Voff       # controller/relay.h                    (1 branch)
+    XCT  p q s1 ct s2  n_total      # linear/transformer_center_tap.h       (3 branches)
 
 Node id -1 = unconnected pin.  Values are printed with %.17g so every consumer reads the same doubles.
 """
@@ -41,11 +43,11 @@ from dataclasses import dataclass, field
 import numpy as np
 
 KINDS = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "FBR", "IAC", "VCCS", "VCVS", "CCCS", "CCVS", "OPAMP", "XFMR", "SW", "SAW", "SQR", "PULSE",
-         "TRI", "KL", "NMOS", "PMOS", "NPN", "PNP")
+         "TRI", "KL", "NMOS", "PMOS", "NPN", "PNP", "RELAY", "XCT")
 NPINS = {"R": 2, "C": 2, "L": 2, "VDC": 2, "VAC": 2, "IDC": 2, "D": 2, "FBR": 4, "IAC": 2, "VCCS": 4, "VCVS": 4, "CCCS": 4, "CCVS": 4,
-         "OPAMP": 4, "XFMR": 4, "SW": 2, "SAW": 2, "SQR": 2, "PULSE": 2, "TRI": 2, "KL": 4, "NMOS": 3, "PMOS": 3, "NPN": 3, "PNP": 3}
+         "OPAMP": 4, "XFMR": 4, "SW": 2, "SAW": 2, "SQR": 2, "PULSE": 2, "TRI": 2, "KL": 4, "NMOS": 3, "PMOS": 3, "NPN": 3, "PNP": 3, "RELAY": 4, "XCT": 5}
 NBRANCH = {"R": 0, "C": 0, "L": 1, "VDC": 1, "VAC": 1, "IDC": 0, "D": 0, "FBR": 0, "IAC": 0, "VCCS": 0, "VCVS": 1, "CCCS": 1, "CCVS": 2,
-           "OPAMP": 1, "XFMR": 2, "SW": 1, "SAW": 1, "SQR": 1, "PULSE": 1, "TRI": 1, "KL": 2, "NMOS": 0, "PMOS": 0, "NPN": 0, "PNP": 0}
+           "OPAMP": 1, "XFMR": 2, "SW": 1, "SAW": 1, "SQR": 1, "PULSE": 1, "TRI": 1, "KL": 2, "NMOS": 0, "PMOS": 0, "NPN": 0, "PNP": 0, "RELAY": 1, "XCT": 3}
 # defaults follow the reference structs' member initialisers
 DEFAULTS = {
     "R": (10.0,),
@@ -67,6 +69,7 @@ DEFAULTS = {
     "KL": (1e-3, 1e-3, 0.99),
     "NMOS": (1e-3, 0.0, 1.0), "PMOS": (1e-3, 0.0, 1.0),                   # nmosfet.h:19-21
     "NPN": (1e-16, 1.0, 100.0, 27.0, 1.0), "PNP": (1e-16, 1.0, 100.0, 27.0, 1.0),   # BJT_NPN.h:15-19
+    "RELAY": (5.0, 3.0), "XCT": (1.0,),
 }
 # generators -> (type code of PE_HIP_VGEN, positions of Vh Vl freq duty phase tr tf in the deck's parameter tuple, -1 = absent)
 VGEN_LAYOUT = {"SAW": (0, (0, 1, 2, -1, 3, -1, -1)), "SQR": (1, (0, 1, 2, 3, 4, -1, -1)), "PULSE": (2, (0, 1, 2, 3, 4, 5, 6)),
@@ -102,7 +105,7 @@ class Deck:
         return sum(1 for k, _, _ in self.devices if k == kind)
 
     def has_nonlinear(self) -> bool:
-        return any(k in ("D", "FBR", "NMOS", "PMOS", "NPN", "PNP") for k, _, _ in self.devices)
+        return any(k in ("D", "FBR", "NMOS", "PMOS", "NPN", "PNP", "RELAY") for k, _, _ in self.devices)
 
     def dumps(self) -> str:
         out = [f"nodes {self.n_nodes}"]
@@ -541,4 +544,28 @@ def bjt_amp_tr() -> Deck:
     d.add("C", (4, 2), 1e-6)
     d.add("C", (3, 5), 1e-7)
     d.add("R", (5, 0), 1e4)
+    return d
+
+
+def center_tap_ratio() -> Deck:
+    """test/0005.models/transformer_center_tap_ratio.cpp: 4 V primary, n_total 2: +1 V / -1 V on the two 100 Ohm half loads."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 4.0)
+    d.add("XCT", (1, 0, 2, 0, 3), 2.0)
+    d.add("R", (2, 0), 100.0)
+    d.add("R", (3, 0), 100.0)
+    return d
+
+
+def relay_ramp() -> Deck:
+    """test/0005.models/relay_hysteresis.cpp as ONE transient: a 100 Hz triangle (0..8 V) drives the coil of a relay
+    (Von 5, Voff 3) whose contact switches 1 V onto 100 Ohm: closes on the way up past 5 V, opens on the way down past 3 V."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VDC", (1, 0), 1.0)
+    d.add("TRI", (3, 0), 8.0, 0.0, 100.0, 0.0)
+    d.add("R", (2, 0), 100.0)
+    d.add("RELAY", (3, 0, 1, 2), 5.0, 3.0)
+    d.add("R", (3, 0), 1e4)
     return d

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("PE_HIP_LIB", os.path.join(_HERE, "libpe_hip.so"))
 # pe_hip_kind
 R, CAP, L, VDC, VAC, IDC, DIODE = 1, 2, 3, 4, 5, 6, 7
 IAC, VCCS, VCVS, CCCS, CCVS, OPAMP, XFMR, SWITCH, VGEN, COUPLED_L = 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
-NMOS, PMOS, BJT_NPN, BJT_PNP = 18, 19, 20, 21
+NMOS, PMOS, BJT_NPN, BJT_PNP, RELAY, XFMR_CT = 18, 19, 20, 21, 22, 23
 DIODE_NPARAM = 11
 MODE_OP, MODE_DC, MODE_TR, MODE_TROP = 0, 1, 4, 5
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
@@ -137,7 +137,7 @@ def deck_tables(deck, batch=1, overrides=None, n_drives=0):
     overrides = overrides or {}
     from .deck import NBRANCH, VGEN_LAYOUT
     names = ("R", "C", "L", "VDC", "VAC", "IDC", "D", "IAC", "VCCS", "VCVS", "CCCS", "CCVS", "OPAMP", "XFMR", "SW", "VGEN", "KL", "NMOS", "PMOS",
-             "NPN", "PNP")
+             "NPN", "PNP", "RELAY", "XCT")
     groups = {k: {"nodes": [], "branch": [], "par": []} for k in names}
     k = n_drives
     for kind, nodes, par in deck.devices:
@@ -162,7 +162,7 @@ def deck_tables(deck, batch=1, overrides=None, n_drives=0):
             k += 1
     code = {"R": R, "C": CAP, "L": L, "VDC": VDC, "VAC": VAC, "IDC": IDC, "D": DIODE, "IAC": IAC, "VCCS": VCCS, "VCVS": VCVS, "CCCS": CCCS,
             "CCVS": CCVS, "OPAMP": OPAMP, "XFMR": XFMR, "SW": SWITCH, "VGEN": VGEN, "KL": COUPLED_L, "NMOS": NMOS, "PMOS": PMOS,
-            "NPN": BJT_NPN, "PNP": BJT_PNP}
+            "NPN": BJT_NPN, "PNP": BJT_PNP, "RELAY": RELAY, "XCT": XFMR_CT}
     tables = []
     for name, g in groups.items():
         if not g["nodes"]:

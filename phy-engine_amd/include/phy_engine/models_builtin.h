@@ -730,4 +730,71 @@ namespace phy_engine::model
         return true;
     }
 
+
+    // ------------------------------------------------------------------ relay (controller/relay.h): coil C+ C-, contact A B
+    struct relay
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Relay"};
+        inline static constexpr model_device_type device_type{model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"RELAY"};
+        pin pins[4]{{{u8"C+"}}, {{u8"C-"}}, {{u8"A"}}, {{u8"B"}}};
+        branch branches{};
+        double Von{5.0};
+        double Voff{3.0};
+        bool engaged{};  // lives on the device (per instance); this member mirrors the reference's layout only
+    };
+    inline bool set_attribute_define(model_reserve_type_t<relay>, relay& m, ::std::size_t n, variant vi) noexcept
+    {
+        double relay::* const f[2] = {&relay::Von, &relay::Voff};
+        return n < 2 && details::set_d(f[n], m, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<relay>, relay const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.Von) : n == 1 ? details::dvar(m.Voff) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<relay>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[2] = {u8"Von", u8"Voff"};
+        return n < 2 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<relay>, relay& m) noexcept { return {m.pins, 4}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<relay>, relay& m) noexcept { return {&m.branches, 1}; }
+    inline bool gpu_table_define(model_reserve_type_t<relay>, relay const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_RELAY, 0, 1, 0, {m.Von, m.Voff}, 2, 3, -1};
+        return true;
+    }
+
+    // ------------------------------------------------------------------ transformer_center_tap (linear/transformer_center_tap.h)
+    struct transformer_center_tap
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"Transformer Center Tap"};
+        inline static constexpr model_device_type device_type{model_device_type::linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"TXCT"};
+        double n_total{1.0};
+        double n_half{};  // 2 * n_total, derived where the stamp is built (pe_circuit.cpp)
+        pin pins[5]{{{u8"P"}}, {{u8"Q"}}, {{u8"S1"}}, {{u8"CT"}}, {{u8"S2"}}};
+        branch branches[3]{};  // kP, kH1, kH2
+    };
+    inline bool set_attribute_define(model_reserve_type_t<transformer_center_tap>, transformer_center_tap& m, ::std::size_t n, variant vi) noexcept
+    {
+        return details::set1(&transformer_center_tap::n_total, m, n, vi);
+    }
+    inline variant get_attribute_define(model_reserve_type_t<transformer_center_tap>, transformer_center_tap const& m, ::std::size_t n) noexcept
+    {
+        return n == 0 ? details::dvar(m.n_total) : variant{};
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<transformer_center_tap>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"n_total"} : ::fast_io::u8string_view{};
+    }
+    inline pin_view generate_pin_view_define(model_reserve_type_t<transformer_center_tap>, transformer_center_tap& m) noexcept { return {m.pins, 5}; }
+    inline branch_view generate_branch_view_define(model_reserve_type_t<transformer_center_tap>, transformer_center_tap& m) noexcept { return {m.branches, 3}; }
+    inline bool gpu_table_define(model_reserve_type_t<transformer_center_tap>, transformer_center_tap const& m, gpu_table_rows& t) noexcept
+    {
+        t.count = 1;
+        t.row[0] = {PE_HIP_XFMR_CT, 0, 1, 0, {m.n_total}, 2, 3, 1, 4, 2};
+        return true;
+    }
 }  // namespace phy_engine::model

@@ -285,9 +285,16 @@ namespace phy_engine
             double params[PE_HIP_DIODE_NPARAM]{};
             int pin_c{-1}, pin_d{-1}; // third / fourth pin of the four-pin kinds (pe_hip.h)
             int branch2{-1};          // second branch row of the two-branch kinds
+            int pin_e{-1};            // fifth pin / third branch row (center-tap transformer)
+            int branch3{-1};
         };
         // node / branch / parameter columns per device of a pe_hip_kind (pe_hip.h)
-        inline constexpr int gpu_kind_pins(int k) noexcept { return k >= PE_HIP_NMOS ? 3 : ((k <= PE_HIP_IAC || k == PE_HIP_SWITCH || k == PE_HIP_VGEN) ? 2 : 4); }
+        inline constexpr int gpu_kind_pins(int k) noexcept
+        {
+            if(k == PE_HIP_XFMR_CT) return 5;
+            if(k == PE_HIP_RELAY) return 4;
+            return k >= PE_HIP_NMOS ? 3 : ((k <= PE_HIP_IAC || k == PE_HIP_SWITCH || k == PE_HIP_VGEN) ? 2 : 4);
+        }
         inline constexpr int gpu_kind_branches(int k) noexcept
         {
             switch(k)
@@ -299,7 +306,9 @@ namespace phy_engine
                 case PE_HIP_CCCS:
                 case PE_HIP_OPAMP:
                 case PE_HIP_SWITCH:
+                case PE_HIP_RELAY:
                 case PE_HIP_VGEN: return 1;
+                case PE_HIP_XFMR_CT: return 3;
                 case PE_HIP_CCVS:
                 case PE_HIP_XFMR:
                 case PE_HIP_COUPLED_L: return 2;
@@ -317,6 +326,7 @@ namespace phy_engine
                 case PE_HIP_PMOS: return 3;
                 case PE_HIP_BJT_NPN:
                 case PE_HIP_BJT_PNP: return 5;
+                case PE_HIP_RELAY: return 2;
                 case PE_HIP_DIODE: return PE_HIP_DIODE_NPARAM;
                 case PE_HIP_VGEN: return PE_HIP_VGEN_NPARAM;
                 default: return 1;
@@ -931,9 +941,11 @@ namespace phy_engine
                         t.nodes.push_back(node_id(row.pin_a));
                         t.nodes.push_back(node_id(row.pin_b));
                         if(model::gpu_kind_pins(row.kind) >= 3) t.nodes.push_back(node_id(row.pin_c));
-                        if(model::gpu_kind_pins(row.kind) == 4) t.nodes.push_back(node_id(row.pin_d));
+                        if(model::gpu_kind_pins(row.kind) >= 4) t.nodes.push_back(node_id(row.pin_d));
+                        if(model::gpu_kind_pins(row.kind) == 5) t.nodes.push_back(node_id(row.pin_e));
                         if(row.branch >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch);
                         if(row.branch2 >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch2);
+                        if(row.branch3 >= 0) t.branch.push_back(static_cast<int>(branch0) + row.branch3);
                         int const ncol = model::gpu_kind_ncol(row.kind);
                         for(int q = 0; q < ncol; ++q) t.params.push_back(row.params[q]);
                     }

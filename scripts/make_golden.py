@@ -80,6 +80,10 @@ CASES["bjt_amp_tr"] = (("bjt_amp_tr", {}), "TR", 1e-6, 300, 0.0, "1,10,100,300",
 CASES["bjt_amp_trop_fail"] = (("bjt_amp_tr", {}), "TROP", 1e-6, 50, 0.0, "0,1,50", True)   # cold-start OP of an unlimited exp: the reference gives up
 
 
+CASES["center_tap_ratio"] = (("center_tap_ratio", {}), "DC", 0.0, 0, 0.0, "", True)
+CASES["relay_ramp_tr"] = (("relay_ramp", {}), "TR", 1e-4, 200, 0.0, "1,30,62,63,64,70,100,130,137,138,139,150,200", True)
+
+
 def tt_diode_deck():
     """test/0004.solver/pn_junction_tt_tr.cpp: VDC 0.7 + VAC 0.1 (omega*dt = pi/2) across a tt=1e-9 diode."""
     import math

@@ -7,7 +7,9 @@
 #include <numbers>
 
 #include <phy_engine/circuits/circuit.h>
+#include <phy_engine/model/models/controller/relay.h>
 #include <phy_engine/model/models/controller/switch.h>
+#include <phy_engine/model/models/linear/transformer_center_tap.h>
 #include <phy_engine/model/models/generator/pulse.h>
 #include <phy_engine/model/models/generator/sawtooth.h>
 #include <phy_engine/model/models/generator/square.h>
@@ -262,6 +264,63 @@ int main()
         wire2(nl, src, gnd, n1);
         wire2(nl, rl, n1, gnd);
         if(run(c, "iac dc")) expect("iac dc", v(n1), 0.0, 0.0);
+    }
+    {   // center-tap transformer, n_total = 2: +-1 V on the half windings (test/0005.models/transformer_center_tap_ratio.cpp)
+        circ c{};
+        c.set_analyze_type(::phy_engine::analyze_type::DC);
+        auto& nl{c.get_netlist()};
+        auto [src, p0]{add_model(nl, pm::VDC{.V = 4.0})};
+        auto [tx, p1]{add_model(nl, pm::transformer_center_tap{.n_total = 2.0})};
+        auto [r1, p2]{add_model(nl, pm::resistance{.r = 100.0})};
+        auto [r2, p3]{add_model(nl, pm::resistance{.r = 100.0})};
+        auto& np{create_node(nl)};
+        auto& s1{create_node(nl)};
+        auto& s2{create_node(nl)};
+        auto& gnd{nl.ground_node};
+        wire2(nl, src, np, gnd);
+        add_to_node(nl, *tx, 0, np);
+        add_to_node(nl, *tx, 1, gnd);
+        add_to_node(nl, *tx, 2, s1);
+        add_to_node(nl, *tx, 3, gnd);
+        add_to_node(nl, *tx, 4, s2);
+        wire2(nl, r1, s1, gnd);
+        wire2(nl, r2, s2, gnd);
+        if(run(c, "center tap"))
+        {
+            expect("center tap vs1", v(s1), 1.0, 1e-9);
+            expect("center tap vs2", v(s2), -1.0, 1e-9);
+            expect("center tap branches", static_cast<double>(tx->ptr->generate_branch_view().size), 3.0, 0.0);
+        }
+    }
+    {   // relay hysteresis (test/0005.models/relay_hysteresis.cpp): 0 V open, 6 V closes, 4 V stays closed, 2 V opens
+        circ c{};
+        c.set_analyze_type(::phy_engine::analyze_type::DC);
+        auto& nl{c.get_netlist()};
+        auto [src, p0]{add_model(nl, pm::VDC{.V = 1.0})};
+        auto [ctl, p1]{add_model(nl, pm::VDC{.V = 0.0})};
+        auto [rl, p2]{add_model(nl, pm::resistance{.r = 100.0})};
+        pm::relay r0{};
+        r0.Von = 5.0;
+        r0.Voff = 3.0;
+        auto [ry, p3]{add_model(nl, r0)};
+        auto& a{create_node(nl)};
+        auto& b{create_node(nl)};
+        auto& nc{create_node(nl)};
+        auto& gnd{nl.ground_node};
+        wire2(nl, src, a, gnd);
+        wire2(nl, rl, b, gnd);
+        wire2(nl, ctl, nc, gnd);
+        wire4(nl, ry, nc, gnd, a, b);
+        double const drive[4] = {0.0, 6.0, 4.0, 2.0};
+        double const want[4] = {0.0, 1.0, 1.0, 0.0};
+        for(int i = 0; i < 4; ++i)
+        {
+            pm::variant vv{};
+            vv.d = drive[i];
+            vv.type = pm::variant_type::d;
+            if(!ctl->ptr->set_attribute(0, vv)) ++failures;
+            if(run(c, "relay")) expect("relay contact voltage", v(b), want[i], 1e-6);
+        }
     }
     if(failures) std::fprintf(stderr, "linear_models: %d failure(s)\n", failures);
     return failures ? 1 : 0;

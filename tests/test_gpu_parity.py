@@ -53,9 +53,11 @@ def test_stamper_golden_parity(eng, name, tol):
     assert list(trace) == meta["newton_iters"]
 
 
-@pytest.mark.parametrize("name", ["nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr"])
+@pytest.mark.parametrize("name", ["nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr", "center_tap_ratio",
+                                  "relay_ramp_tr"])
 def test_three_pin_nonlinear_golden_parity(eng, name):
-    """Level-1 MOSFETs and the forward-active BJT (device kinds 18-21): same Newton trajectory as the reference."""
+    """Level-1 MOSFETs and the forward-active BJT (device kinds 18-21), the relay with its hysteresis state (22) and the
+    center-tap transformer (23): same Newton trajectory as the reference."""
     meta, gx, deck = golden(name)
     snaps, trace, fail = run_engine_case(eng, meta, deck)
     assert fail == -1 and meta["fail_step"] == -1

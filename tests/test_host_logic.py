@@ -130,7 +130,7 @@ def emu_lib():
                                            "switch_open_dc", "switch_closed_dc", "switch_open_ropen1e6_dc", "generators_tr", "generators_trop",
                                            "iac_rc_tr", "iac_rc_dc", "iac_rc_trop", "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop",
                                            "coupled_l_dc", "controlled_mix_tr", "nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op",
-                                           "cmos_inverter_tr", "bjt_amp_tr")])
+                                           "cmos_inverter_tr", "bjt_amp_tr", "center_tap_ratio", "relay_ramp_tr")])
 def test_front_code_indexing_under_host_emulation(emu_lib, name, parts):
     """Runs pe_front.hpp + pe_engine.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
     parts > 1 = the multi-workgroup schedule (level-1 cut + top levels, one launch per phase); parts < 0 = the same

@@ -13,7 +13,7 @@ FAST = ["rc_step", "rl_step", "rlc_series_vl", "rlc_series_vl_trop", "divider_dc
 STAMPERS = ["vccs_dc", "vcvs_gain", "cccs_dc", "ccvs_dc", "op_amp_follower", "transformer_ratio", "generator_dc", "switch_open_dc",
             "switch_closed_dc", "switch_open_ropen1e6_dc", "generators_tr", "generators_trop", "iac_rc_tr", "iac_rc_dc", "iac_rc_trop",
             "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop", "coupled_l_dc", "controlled_mix_tr",
-            "nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr"]
+            "nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op", "cmos_inverter_tr", "bjt_amp_tr", "center_tap_ratio", "relay_ramp_tr"]
 
 
 def run_oracle(orc, meta, deck):
