@@ -8,7 +8,8 @@
  * 14 transformer{n}, 15 coupled inductors{L1,L2,k}, 16 center-tap transformer{n_total}, 17 op-amp{mu}, 18 relay{Von,Voff}, 20 sawtooth{Vh,Vl,f,phase}, 21 square{Vh,Vl,f,duty,phase},
  * 22 pulse{Vh,Vl,f,duty,phase,tr,tf}, 23 triangle{Vh,Vl,f,phase}, 50/51 BJT NPN/PNP{Is,N,BetaF,Temp,Area},
  * 52/53 level-1 N/PMOSFET{Kp,lambda,Vth}.  Every analysis runs on the MI355X through include/pe_hip.h.  Other element codes
- * (BSIM3, the digital gate library beyond the C4 subset, Verilog) are rejected.
+ * Mixed-signal: 19 comparator{Ll,Hl}, 200 INPUT{state}, 201 OUTPUT, 202 OR, 203 YES, 204 AND, 205 NOT, 206 XOR, 207 XNOR, 208 NAND,
+ * 209 NOR (event logic on the host, circuit_digital_clk).  Other element codes (BSIM3, tri-state / flip-flops / blocks, Verilog) are rejected.
  */
 #ifndef PHY_ENGINE_DLL_API_SUBSET_H
 #define PHY_ENGINE_DLL_API_SUBSET_H
@@ -41,6 +42,11 @@ int circuit_sample(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t
                    size_t* current_ord, bool* digital, size_t* digital_ord);
 int circuit_sample_u8(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, double* voltage, size_t* voltage_ord, double* current,
                       size_t* current_ord, uint8_t* digital, size_t* digital_ord);
+/* dll_api.h:222-234: digital pins report their 4-state value (0 L, 1 H, 2 X, 3 Z); set one digital attribute of a component */
+int circuit_sample_digital_state_u8(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, double* voltage, size_t* voltage_ord,
+                                    double* current, size_t* current_ord, uint8_t* digital, size_t* digital_ord);
+int circuit_set_model_digital(void* circuit_ptr, size_t vec_pos, size_t chunk_pos, size_t attribute_index, uint8_t state);
+void phy_engine_string_free(char* s); /* dll_api.h:47 (nothing in this subset returns an owned string; kept for loaders that resolve it) */
 int analyze_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, int* changed_ele, size_t* changed_ind, double* changed_prop,
                     size_t prop_size, double* voltage, size_t* voltage_ord, double* current, size_t* current_ord, bool* digital, size_t* digital_ord);
 

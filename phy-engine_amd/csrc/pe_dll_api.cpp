@@ -115,6 +115,33 @@ namespace
                 out = add_model(nl, g);
                 return true;
             }
+            // ---- mixed-signal subset (19, 200, 201, 204, 205) + the other two-input gates and the buffer
+            case 19:
+            {
+                comparator c{};
+                c.Ll = take();
+                c.Hl = take();
+                out = add_model(nl, c);
+                return true;
+            }
+            case 200:
+            {
+                // INPUT{state: 0 L, 1 H, 2 X, 3 Z}
+                int const st = static_cast<int>(take());
+                INPUT in{};
+                in.outputA = st == 0 ? digital_node_statement_t::L : st == 1 ? digital_node_statement_t::H : st == 3 ? digital_node_statement_t::Z : digital_node_statement_t::X;
+                out = add_model(nl, in);
+                return true;
+            }
+            case 201: out = add_model(nl, OUTPUT{}); return true;
+            case 202: out = add_model(nl, OR{}); return true;
+            case 203: out = add_model(nl, YES{}); return true;
+            case 204: out = add_model(nl, AND{}); return true;
+            case 205: out = add_model(nl, NOT{}); return true;
+            case 206: out = add_model(nl, XOR{}); return true;
+            case 207: out = add_model(nl, XNOR{}); return true;
+            case 208: out = add_model(nl, NAND{}); return true;
+            case 209: out = add_model(nl, NOR{}); return true;
             case 50:
             case 51:
             {
@@ -394,7 +421,8 @@ int circuit_analyze(void* circuit_ptr)
 int circuit_digital_clk(void* circuit_ptr)
 {
     if(!circuit_ptr) return 1;
-    return 0;  // no digital models in the loader subset: an empty tick
+    static_cast<pe::circult*>(circuit_ptr)->digital_clk();  // host event queue (circuit.h:348-354); analog side untouched
+    return 0;
 }
 
 // src/dll_main.cpp:2269-2305
@@ -429,6 +457,44 @@ int circuit_sample_u8(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, siz
 
 // src/dll_main.cpp:2883-2934: apply (element, attribute index, value) updates, analyze, sample.
 // Returns 1 when the analysis fails and -- like the reference -- 0 when a required pointer is null.
+// dll_api.h:222-234: like circuit_sample_u8 but every digital pin reports its 4-state value (0 L, 1 H, 2 X, 3 Z; X for analog pins)
+int circuit_sample_digital_state_u8(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, double* voltage, size_t* voltage_ord,
+                                    double* current, size_t* current_ord, uint8_t* digital, size_t* digital_ord)
+{
+    if(sample_impl<uint8_t>(circuit_ptr, vec_pos, chunk_pos, comp_size, voltage, voltage_ord, current, current_ord, digital, digital_ord) != 0) return 1;
+    auto& nl = static_cast<pe::circult*>(circuit_ptr)->get_netlist();
+    for(size_t i = 0; i < comp_size; ++i)
+    {
+        auto* m = get_model(nl, vec_pos[i], chunk_pos[i]);
+        if(!m || !m->ptr) continue;
+        auto const pv = m->ptr->generate_pin_view();
+        for(size_t j = 0; j < pv.size; ++j)
+        {
+            auto const* node = pv.pins[j].nodes;
+            uint8_t v = static_cast<uint8_t>(pe::model::digital_node_statement_t::X);
+            if(node && node->num_of_analog_node == 0) v = static_cast<uint8_t>(node->node_information.dn.state);
+            digital[digital_ord[i] + j] = v;
+        }
+    }
+    return 0;
+}
+
+// dll_api.h:234: set a digital attribute (e.g. INPUT's value) of one component: 0 L, 1 H, 2 X, 3 Z
+int circuit_set_model_digital(void* circuit_ptr, size_t vec_pos, size_t chunk_pos, size_t attribute_index, uint8_t state)
+{
+    if(!circuit_ptr) return 1;
+    auto& nl = static_cast<pe::circult*>(circuit_ptr)->get_netlist();
+    auto* m = get_model(nl, vec_pos, chunk_pos);
+    if(!m || !m->ptr) return 2;
+    using st = pe::model::digital_node_statement_t;
+    pe::model::variant vi{};
+    vi.digital = state == 0 ? st::L : state == 1 ? st::H : state == 3 ? st::Z : st::X;
+    vi.type = pe::model::variant_type::digital;
+    return m->ptr->set_attribute(attribute_index, vi) ? 0 : 3;
+}
+
+void phy_engine_string_free(char* s) { std::free(s); }
+
 int analyze_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos, size_t comp_size, int* changed_ele, size_t* changed_ind, double* changed_prop,
                     size_t prop_size, double* voltage, size_t* voltage_ord, double* current, size_t* current_ord, bool* digital, size_t* digital_ord)
 {

@@ -187,10 +187,12 @@ namespace phy_engine::model
         return details::drive_output(g, o, ~details::read_input(g, g.inA, i, now), table);
     }
 
-    template <int OP>  // 0: AND, 1: OR
+    // two-input gates (digital/logical/and.h, or.h, xor.h, xnor.h, nand.h, nor.h): same input sampling, output = op(a, b)
+    template <int OP>  // 0 AND, 1 OR, 2 XOR, 3 XNOR, 4 NAND, 5 NOR
     struct gate2
     {
-        inline static constexpr ::fast_io::u8string_view model_name{OP == 0 ? ::fast_io::u8string_view{u8"AND"} : ::fast_io::u8string_view{u8"OR"}};
+        inline static constexpr ::fast_io::u8string_view names[6] = {u8"AND", u8"OR", u8"XOR", u8"XNOR", u8"NAND", u8"NOR"};
+        inline static constexpr ::fast_io::u8string_view model_name{names[OP]};
         inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
         inline static constexpr model_device_type device_type{model_device_type::digital};
         inline static constexpr ::fast_io::u8string_view identification_name{model_name};
@@ -201,6 +203,10 @@ namespace phy_engine::model
     };
     using AND = gate2<0>;
     using OR = gate2<1>;
+    using XOR = gate2<2>;
+    using XNOR = gate2<3>;
+    using NAND = gate2<4>;
+    using NOR = gate2<5>;
     template <int OP>
     inline pin_view generate_pin_view_define(model_reserve_type_t<gate2<OP>>, gate2<OP>& g) noexcept { return {g.pins, 3}; }
     template <int OP>
@@ -214,7 +220,42 @@ namespace phy_engine::model
         if(!a || !b || !o) return {};
         auto const va = details::read_input(g, g.inA, a, now);
         auto const vb = details::read_input(g, g.inB, b, now);
-        return details::drive_output(g, o, OP == 0 ? (va & vb) : (va | vb), table);
+        digital_node_statement_t r{};
+        if constexpr(OP == 0) r = va & vb;
+        else if constexpr(OP == 1)
+            r = va | vb;
+        else if constexpr(OP == 2)
+            r = va ^ vb;
+        else if constexpr(OP == 3)
+            r = ~(va ^ vb);
+        else if constexpr(OP == 4)
+            r = ~(va & vb);
+        else
+            r = ~(va | vb);
+        return details::drive_output(g, o, r, table);
+    }
+
+    // ------------------------------------------------------------------ YES buffer (digital/logical/yes.h)
+    struct YES
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"YES"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"YES"};
+        pin pins[2]{{{u8"i"}}, {{u8"o"}}};
+        double Ll{0.0}, Hl{5.0}, Tsu{1e-9}, Th{5e-10};
+        details::analog_input_t inA{};
+        digital_node_statement_t last_outputA{digital_node_statement_t::X};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<YES>, YES& g) noexcept { return {g.pins, 2}; }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<YES>, YES& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double now,
+                                                                                       digital_update_method_t) noexcept
+    {
+        auto* i = g.pins[0].nodes;
+        auto* o = g.pins[1].nodes;
+        if(!i || !o) return {};
+        return details::drive_output(g, o, details::read_input(g, g.inA, i, now), table);
     }
 
     // ------------------------------------------------------------------ OUTPUT probe (digital/logical/output.h): attribute 0 = value

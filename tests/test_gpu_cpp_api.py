@@ -6,6 +6,10 @@ exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64).  Each mi
   op_pn_junction  test/0011.nonlinear/op_pn_junction.cpp
   bridge_tr       config C2 through full_bridge_rectifier + refusal of a host-only user model
   dll_smoke       test/0008.dll/dll_main_smoke.cpp
+  linear_models   the known answers of test/0005.models/{vccs_dc,vcvs_gain,cccs_dc,ccvs_dc,op_amp_follower,transformer_ratio,
+                  transformer_center_tap_ratio,switch_r_open,generator_dc,coupled_inductors_TR,relay_hysteresis}.cpp
+  dll_elements / transistors / dll_mixed_signal   the loader's element codes 7-23, 50-53, 19 + 200-209 (dll_api.h:51-135)
+The same programs also run on the CPU against the host emulation of the kernels (tests/emu) to check the host-side logic.
 """
 import os
 import subprocess
@@ -15,13 +19,28 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors"]  # adc_flash: checked against the golden below
+TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")
 def built():
     subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
     return os.path.join(CPP, "_build")
+
+
+@pytest.fixture(scope="module")
+def built_emu():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu")], check=True, capture_output=True)
+    subprocess.run(["make", "-j8", "-C", CPP, "emu"], check=True, capture_output=True)
+    return os.path.join(CPP, "_build_emu")
+
+
+@pytest.mark.parametrize("name", TESTS)
+def test_reference_style_program_under_host_emulation(built_emu, name):
+    """CPU: plug-in API, loader and digital event queue logic with the kernels emulated by a one-thread team (tests/emu,
+    test infrastructure).  The parity proper is the GPU run of the same programs below."""
+    out = subprocess.run([os.path.join(built_emu, name)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, f"{name} exited {out.returncode}: {out.stderr}"
 
 
 @pytest.mark.gpu
