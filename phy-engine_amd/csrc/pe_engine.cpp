@@ -190,7 +190,7 @@ namespace
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
         V.wave_p = so.wave_p;
-        V.lds_slot = so.wave_m * so.wave_m;  // a wavefront's slot holds its fronts whole (order <= wave_m: pe_front.hpp FULL mode)
+        V.lds_slot = so.wave_m * (so.wave_m + 1);  // a wavefront's slot holds its fronts whole (order <= wave_m) + the right-hand-side column
         V.lds_wave_stage = so.wave_m * so.wave_p;              // a wavefront stages the whole m x p panel of its (small) fronts
         V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
         V.lds_sslot = so.wave_m + V.lds_wave_stage + 64;       // t[m] + staged block + partial sums of one wavefront
@@ -209,7 +209,7 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
-    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows)
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve = 384)
     {
         int const batch = geometry_batch(batch_in);
         pe::SymbolicOptions so{};
@@ -259,10 +259,12 @@ namespace
         int const resident = std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", batch >= 384 ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
         long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
         // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
-        while(static_cast<long long>(so.n_waves) * so.wave_m * so.wave_m > lds_doubles && so.wave_m > 8) --so.wave_m;
+        while(static_cast<long long>(so.n_waves) * so.wave_m * (so.wave_m + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
         so.wave_p = std::min(so.wave_p, so.wave_m);
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
-        so.panel_doubles = lds_doubles - 384;  // large (panel-mode) fronts keep room for their children's staged inverse maps
+        // large (panel-mode) fronts keep room behind the panels for the right-hand-side column (m doubles) and their
+        // children's staged inverse maps
+        so.panel_doubles = std::max<long long>(lds_doubles - panel_reserve, lds_doubles / 2);
         return so;
     }
 
@@ -273,11 +275,17 @@ namespace
         auto const t0 = clk::now();
         std::vector<double> av;
         pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
-        pe::SymbolicOptions const so = symbolic_options(h, h->hc.batch, h->hc.rows);
-        if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
+        pe::SymbolicOptions so = symbolic_options(h, h->hc.batch, h->hc.rows);
+        for(int attempt = 0; attempt < 2; ++attempt)
         {
-            h->sym_class = -1;
-            return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
+            if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
+            {
+                h->sym_class = -1;
+                return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
+            }
+            // a front larger than the reserve behind the panels: analyse again with room for its right-hand-side column
+            if(h->sym.max_m + 8 <= 384 || attempt == 1) break;
+            so = symbolic_options(h, h->hc.batch, h->hc.rows, h->sym.max_m + 72);
         }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
         {

@@ -465,7 +465,7 @@ namespace pe
     // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
     // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
     template <class Team>
-    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, bool profile)
+    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, bool profile, bool fuse)
     {
         int const s = tm.uniform(s_in);
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
@@ -477,15 +477,24 @@ namespace pe
         // child instead of index-dependent pulls.  PANEL mode (large fronts): only the pivot panels live in LDS and the
         // Schur block pulls the children's entries tile by tile through the inverse maps.
         int const ch0 = V.f_child_ptr[s], ch1 = V.f_child_ptr[s + 1];
-        bool const full = m * m <= cap;
+        // FUSED forward substitution (`fuse`): the permuted right-hand side rides through the factorisation as one more
+        // column g[m] of the front -- pivot part from w, update part from the children's update vectors -- so that after the
+        // block loop g[0..p) is the forward-substituted solution of these pivots and g[p..m) this front's update vector.
+        // Saves the separate forward pass over the factor panels whenever a factorisation is followed by a solve.
+        bool const full = m * (m + 1) <= cap;
         bool const chain = !full && ch1 - ch0 == 1 && V.f_u[V.f_child[ch0]] == m;  // then f_rel of the child is the identity
         int const ldu = full ? m : p;
         int const nlds = full ? m * m : m * p + p * u;
         double* Lp = lds;
         double* Up = lds + m * p;
+        double* g = lds + nlds;  // [m] right-hand-side column (fuse)
         int const T = tm.size(), t0 = tm.tid();
+        int const c0 = V.f_col0[s];
+        double* w = V.w + static_cast<long long>(b) * V.rows;
         long long const ck0 = tm.clock();
         for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
+        if(fuse)
+            for(int i = t0; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
         tm.sync_lds();
         // the entries of A owned by this front first: their loads do not depend on anything a previous front wrote, so
         // they overlap with that front's stores still in flight
@@ -608,6 +617,11 @@ namespace pe
                     }
                 }
             }
+            if(fuse)
+            {
+                double const* vc = Sc + n;  // the child's update vector sits behind its update matrix
+                for(int i = t0; i < uc; i += T) g[rel[i]] += vc[i];
+            }
             tm.sync_lds();
         }
         long long const ck1 = tm.clock();
@@ -630,7 +644,8 @@ namespace pe
                 int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
                 int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
                 int const ncols = ncolL + u;              // plus every column of the U panel
-                for(int q = t0; q < nrows + ncols; q += T)
+                int const ngc = fuse ? 1 : 0;             // plus the right-hand-side column
+                for(int q = t0; q < nrows + ncols + ngc; q += T)
                 {
                     double x[NB];
                     if(q < nrows)
@@ -663,7 +678,7 @@ namespace pe
                     {
                         // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
                         int const jc = q - nrows;
-                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : Up + (jc - ncolL) * ldu + k0;
+                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : (jc < ncols ? Up + (jc - ncolL) * ldu + k0 : g + k0);
 #pragma unroll
                         for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
 #pragma unroll
@@ -691,6 +706,15 @@ namespace pe
             // (b) trailing update of both panels, one 16 x 16 tile per wavefront at a time
             {
                 int const r0 = k0 + kb;
+                if(fuse)  // g[r0..m) -= L[r0..m, block] * g[block]: every row of the front, pivot and update part alike
+                    for(int r = r0 + t0; r < m; r += T)
+                    {
+                        double acc = g[r];
+#pragma unroll
+                        for(int kk = 0; kk < NB; ++kk)
+                            if(kk < kb) acc -= Lp[r + (k0 + kk) * m] * g[k0 + kk];
+                        g[r] = acc;
+                    }
                 int const trL = (m - r0 + 15) / 16, tcL = (p - r0 + 15) / 16;   // L panel: rows r0..m, cols r0..p
                 int const trU = (p - r0 + 15) / 16, tcU = (u + 15) / 16;        // U panel: rows r0..p, all columns
                 int const nL = trL * tcL, nU = trU * tcU;
@@ -749,10 +773,11 @@ namespace pe
             // PANEL mode: the children's inverse maps (rows p.. of this front -> child index) are staged behind the panels
             // when they fit, so that a tile's pulls are ONE round of unconditional loads instead of index-dependent ones
             int const nch = ch1 - ch0;
-            long long* csp = reinterpret_cast<long long*>(lds + nlds);  // per child: arena offset of its update matrix,
+            int const ng = fuse ? m + (m & 1) : 0;                      // the right-hand-side column sits right behind the panels
+            long long* csp = reinterpret_cast<long long*>(lds + nlds + ng);  // per child: arena offset of its update matrix,
             int* cuc = reinterpret_cast<int*>(csp + nch);               //            its order,
             int* linv = cuc + nch + (nch & 1);                          //            its inverse map (rows p.. of this front)
-            bool const staged = !full && !chain && (static_cast<long long>(nch) * (u + 3) + 2) * 4 <= static_cast<long long>(cap - nlds) * 8;
+            bool const staged = !full && !chain && (static_cast<long long>(nch) * (u + 3) + 2) * 4 <= static_cast<long long>(cap - nlds - ng) * 8;
             if(staged)
             {
                 for(int q = t0; q < nch; q += T)
@@ -830,6 +855,12 @@ namespace pe
                 });
         }
         long long const ck3 = tm.clock();
+        if(fuse)
+        {
+            for(int i = t0; i < p; i += T) w[c0 + i] = g[i];
+            double* vs = arena + V.f_sptr[s] + static_cast<long long>(u) * u;
+            for(int i = t0; i < u; i += T) vs[i] = g[p + i];
+        }
         double* Lg = fac + V.f_lptr[s];
         if(full)
         {
@@ -859,7 +890,7 @@ namespace pe
 
     // one PART of the tree (single-workgroup mode: part 0 = everything): wave fronts, then the part's cooperative fronts
     template <class Team>
-    PE_DEV bool factor_part(Team const& tm, DevView const& V, int b, int part, double* lds)
+    PE_DEV bool factor_part(Team const& tm, DevView const& V, int b, int part, double* lds, bool fuse)
     {
         int fail = 0;
         long long const c0 = tm.clock();
@@ -871,7 +902,7 @@ namespace pe
                 double* slot = lds + static_cast<long long>(w) * V.lds_slot;
                 int const q1 = tm.uniform(wp[w + 1]);
                 for(int q = tm.uniform(wp[w]); q < q1; ++q)
-                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, false))
+                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, false, fuse))
                     {
                         fail = 1;
                         break;
@@ -880,7 +911,7 @@ namespace pe
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
         for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q)
-            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, true)) return false;
+            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, true, fuse)) return false;
         if(V.prof && tm.tid() == 0 && part == 0)
         {
             V.prof[b * PE_PROF + 1] += c1 - c0;
@@ -890,9 +921,9 @@ namespace pe
     }
 
     template <class Team>
-    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds)
+    PE_DEV bool factor_all(Team const& tm, DevView const& V, int b, double* lds, bool fuse)
     {
-        return factor_part(tm, V, b, 0, lds);
+        return factor_part(tm, V, b, 0, lds, fuse);
     }
 
     // ================================================================================================
@@ -961,7 +992,7 @@ namespace pe
         for(int ch = V.f_child_ptr[s]; ch < V.f_child_ptr[s + 1]; ++ch)
         {
             int const c = V.f_child[ch];
-            double const* uc = arena + V.f_sptr[c];
+            double const* uc = arena + V.f_sptr[c] + static_cast<long long>(V.f_u[c]) * V.f_u[c];  // the vector sits behind the update matrix
             int const* rel = V.f_rel + V.f_rows_ptr[c];
             for(int i = t0; i < V.f_u[c]; i += T) t[rel[i]] += uc[i];
             tm.sync_lds();
@@ -976,7 +1007,7 @@ namespace pe
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
         if(u > 0)
         {
-            double* us = arena + V.f_sptr[s];
+            double* us = arena + V.f_sptr[s] + static_cast<long long>(u) * u;
             if(small)
                 for(int i = t0; i < u; i += T) us[i] = t[p + i];
             else
@@ -1078,17 +1109,26 @@ namespace pe
     }
 
     // single-workgroup mode: the whole tree is part 0
+    // w = P rhs (row permutation of the static pivoting)
     template <class Team>
-    PE_DEV void solve_all(Team const& tm, DevView const& V, int b, double* lds)
+    PE_DEV void permute_rhs(Team const& tm, DevView const& V, int b)
     {
-        int const T = tm.size(), t0 = tm.tid();
         double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
         double* w = V.w + static_cast<long long>(b) * V.rows;
-        double* x = V.x + static_cast<long long>(b) * V.rows;
-        for(int k = t0; k < V.rows; k += T) w[k] = rhs[V.row_src[k]];
+        for(int k = tm.tid(); k < V.rows; k += tm.size()) w[k] = rhs[V.row_src[k]];
         tm.sync();
+    }
+
+    // `forward_done`: the factorisation just ran with the fused forward substitution (w already holds L^-1 P rhs)
+    template <class Team>
+    PE_DEV void solve_all(Team const& tm, DevView const& V, int b, double* lds, bool forward_done)
+    {
+        int const T = tm.size(), t0 = tm.tid();
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double* x = V.x + static_cast<long long>(b) * V.rows;
+        if(!forward_done) permute_rhs(tm, V, b);
         long long const c0 = tm.clock();
-        forward_part(tm, V, b, 0, lds);
+        if(!forward_done) forward_part(tm, V, b, 0, lds);
         long long const c1 = tm.clock();
         backward_part(tm, V, b, 0, lds);
         if(V.prof && t0 == 0)
@@ -1141,9 +1181,10 @@ namespace pe
             if(V.prof && tm.tid() == 0) V.prof[b * PE_PROF + 0] += tm.clock() - c0;
             if(!reuse_factor)
             {
-                if(!factor_all(tm, V, b, lds)) return ST_SINGULAR;
+                permute_rhs(tm, V, b);
+                if(!factor_all(tm, V, b, lds, true)) return ST_SINGULAR;  // forward substitution fused into the factorisation
             }
-            solve_all(tm, V, b, lds);
+            solve_all(tm, V, b, lds, !reuse_factor);
             int nonfinite = 0;
             for(int r = tm.tid(); r < V.rows; r += tm.size())
                 if(!(fabs(x[r]) <= 1.7976931348623157e308)) nonfinite = 1;

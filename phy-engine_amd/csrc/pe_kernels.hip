@@ -274,10 +274,14 @@ namespace pe
         if(b >= V.batch) return;
         HipTeam tm;
         int st = ST_OK;
-        if(do_factor && !factor_all(tm, V, b, pe_lds)) st = ST_SINGULAR;
+        if(do_factor)
+        {
+            permute_rhs(tm, V, b);
+            if(!factor_all(tm, V, b, pe_lds, true)) st = ST_SINGULAR;  // forward substitution rides along
+        }
         if(st == ST_OK)
         {
-            solve_all(tm, V, b, pe_lds);
+            solve_all(tm, V, b, pe_lds, do_factor != 0);
             double const* x = V.x + static_cast<long long>(b) * V.rows;
             int nonfinite = 0;
             for(int r = tm.tid(); r < V.rows; r += tm.size())
@@ -329,7 +333,7 @@ namespace pe
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         HipTeam tm;
-        if(!factor_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        if(!factor_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
     __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_factor_top(DevView V, int level)
@@ -338,7 +342,7 @@ namespace pe
         if(!V.active[b]) return;
         HipTeam tm;
         int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, false) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, false, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)
@@ -435,15 +439,19 @@ namespace pe
         int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
         hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
         hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
+        hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
         if(do_factor)
         {
+            // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
             hipLaunchKernelGGL(k_m2_factor_parts, dim3(V.n_parts, B), dim3(T), lds, st, V);
             for(int l = 0; l < V.n_top_levels; ++l)
                 hipLaunchKernelGGL(k_m2_factor_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
         }
-        hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
-        hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 0);
-        for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 0);
+        else
+        {
+            hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 0);
+            for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 0);
+        }
         for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 1);
         hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 1);
         hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);

@@ -919,7 +919,8 @@ namespace pe
                 fo += p * u;
             }
             S.factor_doubles = fo;
-            // update-matrix arena.  A front whose parent runs on a different executor (or is a top front) keeps its update
+            // update-matrix arena; a slot holds the u x u update matrix followed by the u-vector of the forward substitution
+            // (the right-hand side rides through the factorisation as one more column, pe_front.hpp).  A front whose parent runs on a different executor (or is a top front) keeps its update
             // matrix in a persistent slot; inside one executor the matrices live on TWO LIFO stacks chosen by the parity of
             // the tree depth: a front writes its Schur tiles while later tiles still gather from its children's, so a parent
             // must never overlap its children -- children always sit on the other stack.
@@ -933,7 +934,7 @@ namespace pe
                 if(persistent(s))
                 {
                     S.f_sptr[s] = base;
-                    base += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                    base += static_cast<long long>(S.f_u[s]) * (S.f_u[s] + 1);
                 }
             for(auto const& lst: lists)
             {
@@ -945,12 +946,12 @@ namespace pe
                     for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
                     {
                         int const c = S.f_child[a];
-                        if(!persistent(c)) sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * S.f_u[c];
+                        if(!persistent(c)) sp[depth[c] & 1] -= static_cast<long long>(S.f_u[c]) * (S.f_u[c] + 1);
                     }
                     if(persistent(s)) continue;
                     int const q = depth[s] & 1;
                     rel_off[qi] = sp[q];
-                    sp[q] += static_cast<long long>(S.f_u[s]) * S.f_u[s];
+                    sp[q] += static_cast<long long>(S.f_u[s]) * (S.f_u[s] + 1);
                     peak[q] = std::max(peak[q], sp[q]);
                 }
                 if(sp[0] != 0 || sp[1] != 0)

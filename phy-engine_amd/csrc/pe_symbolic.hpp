@@ -56,7 +56,7 @@ namespace pe
         std::vector<int> asm_pos;               // (r << 16) | c local cell
         std::vector<long long> f_lptr;          // offset of the m x p panel (column major, ld m) in the factor store
         std::vector<long long> f_uptr;          // offset of the p x u panel (column major, ld p)
-        std::vector<long long> f_sptr;          // offset of the u x u update matrix in the stack arena
+        std::vector<long long> f_sptr;          // offset of the u x u update matrix (followed by the u update vector) in the stack arena
         long long factor_doubles{};
         long long arena_doubles{};
         long long work_doubles{};               // (unused)

@@ -129,18 +129,21 @@ namespace pe
             eval_devices(tm, V, b, mode, t, last_step);
             V.flags[b] = 0;
             stamp(tm, V, b);
+            for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
             if(do_factor)
             {
                 for(int q = 0; q < V.n_parts; ++q)
-                    if(!factor_part(tm, V, b, q, mem.data())) V.flags[b] |= 4;
+                    if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
                 for(int l = 0; l < V.n_top_levels; ++l)
                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, false)) V.flags[b] |= 4;
+                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, false, true)) V.flags[b] |= 4;
             }
-            for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
-            for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
-            for(int l = 0; l < V.n_top_levels; ++l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+            else
+            {
+                for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
+                for(int l = 0; l < V.n_top_levels; ++l)
+                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+            }
             for(int l = V.n_top_levels - 1; l >= 0; --l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
@@ -164,10 +167,14 @@ namespace pe
         for(int b = 0; b < V.batch; ++b)
         {
             int st = ST_OK;
-            if(do_factor && !factor_all(tm, V, b, mem.data())) st = ST_SINGULAR;
+            if(do_factor)
+            {
+                permute_rhs(tm, V, b);
+                if(!factor_all(tm, V, b, mem.data(), true)) st = ST_SINGULAR;
+            }
             if(st == ST_OK)
             {
-                solve_all(tm, V, b, mem.data());
+                solve_all(tm, V, b, mem.data(), do_factor);
                 double const* x = V.x + static_cast<long long>(b) * V.rows;
                 for(int r = 0; r < V.rows; ++r)
                     if(!(std::fabs(x[r]) <= 1.7976931348623157e308)) st = ST_SINGULAR;
