@@ -385,34 +385,56 @@ namespace pe
     // ------------------------------------------------------------------------------------------------
     // MNA assembly: every A slot / RHS row gathers its contributions in model order (deterministic)
     // ------------------------------------------------------------------------------------------------
+    // out[s] = sum over the contribution list of slot s, in list order; four slots per thread in flight (the three
+    // dependent loads ptr -> src -> dv of one slot would otherwise be fully exposed)
+    template <class Team>
+    PE_DEV void gather_contributions(Team const& tm, int const* ptr, int const* src, double const* dv, double* out, int n)
+    {
+        int const T = tm.size();
+        for(int base = tm.tid(); base < n; base += 4 * T)
+        {
+            int e[4], end[4];
+            double acc[4];
+#pragma unroll
+            for(int q = 0; q < 4; ++q)
+            {
+                int const s = base + q * T;
+                bool const ok = s < n;
+                e[q] = ok ? ptr[s] : 0;
+                end[q] = ok ? ptr[s + 1] : 0;
+                acc[q] = 0.0;
+            }
+            bool more = true;
+            while(more)
+            {
+                more = false;
+                int sr[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q) sr[q] = e[q] < end[q] ? src[e[q]] : -1;
+                double v[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q) v[q] = dv[sr[q] >= 0 ? sr[q] >> 1 : 0];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    if(sr[q] >= 0)
+                    {
+                        acc[q] = (sr[q] & 1) ? acc[q] - v[q] : acc[q] + v[q];
+                        ++e[q];
+                        more = more || e[q] < end[q];
+                    }
+            }
+#pragma unroll
+            for(int q = 0; q < 4; ++q)
+                if(base + q * T < n) out[base + q * T] = acc[q];
+        }
+    }
+
     template <class Team>
     PE_DEV void stamp(Team const& tm, DevView const& V, int b)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
-        double* a = V.aval + static_cast<long long>(b) * V.nnzA;
-        double* rhs = V.rhs + static_cast<long long>(b) * V.rows;
-        for(int s = tm.tid(); s < V.nnzA; s += tm.size())
-        {
-            double acc = 0.0;
-            for(int e = V.a_ptr[s]; e < V.a_ptr[s + 1]; ++e)
-            {
-                int const src = V.a_src[e];
-                double const v = dv[src >> 1];
-                acc = (src & 1) ? acc - v : acc + v;
-            }
-            a[s] = acc;
-        }
-        for(int r = tm.tid(); r < V.rows; r += tm.size())
-        {
-            double acc = 0.0;
-            for(int e = V.b_ptr[r]; e < V.b_ptr[r + 1]; ++e)
-            {
-                int const src = V.b_src[e];
-                double const v = dv[src >> 1];
-                acc = (src & 1) ? acc - v : acc + v;
-            }
-            rhs[r] = acc;
-        }
+        gather_contributions(tm, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, V.nnzA);
+        gather_contributions(tm, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, V.rows);
     }
 
     // ================================================================================================
@@ -1171,6 +1193,7 @@ namespace pe
         int const iters = V.nonlinear ? V.max_newton : 1;
         for(int it = 0; it < iters; ++it)
         {
+            long long const cb0 = tm.clock();
             if(V.nonlinear)
                 for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
             long long const c0 = tm.clock();
@@ -1185,12 +1208,15 @@ namespace pe
                 if(!factor_all(tm, V, b, lds, true)) return ST_SINGULAR;  // forward substitution fused into the factorisation
             }
             solve_all(tm, V, b, lds, !reuse_factor);
+            long long const cb1 = tm.clock();
             int nonfinite = 0;
             for(int r = tm.tid(); r < V.rows; r += tm.size())
                 if(!(fabs(x[r]) <= 1.7976931348623157e308)) nonfinite = 1;
             if(tm.sync_or(nonfinite)) return ST_SINGULAR;
             if(!V.nonlinear) return 1;
-            if(!tm.sync_or(newton_violations(tm, V, b))) return it + 1;
+            int const viol = tm.sync_or(newton_violations(tm, V, b));
+            if(V.prof && tm.tid() == 0) V.prof[b * PE_PROF + 4] += (c0 - cb0) + (tm.clock() - cb1);  // Newton bookkeeping
+            if(!viol) return it + 1;
         }
         return ST_NO_CONVERGENCE;
     }
