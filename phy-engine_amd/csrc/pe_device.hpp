@@ -111,6 +111,7 @@ namespace pe
         int* active;            // [.] multi-workgroup mode: instances still iterating
         int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)
+        int keep_l21;           // 1: a later launch may reuse the factors with a separate forward pass (linear circuit, refactor_every_solve = 0)
         int wave_m, wave_p, max_m, max_p;
         int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)
         int lds_sslot;          // doubles of one wavefront's solve scratch

@@ -141,6 +141,7 @@ namespace
         V.i_abstol = o.i_abstol > 0.0 ? o.i_abstol : 1e-12;
         V.i_reltol = o.i_reltol > 0.0 ? o.i_reltol : V.v_reltol;
         V.max_newton = o.max_newton > 0 ? o.max_newton : 64;
+        V.keep_l21 = o.refactor_every_solve ? 0 : 1;  // (only a linear circuit actually reuses; a non-linear one refactors anyway)
         V.r_open = r_open_of(h);
     }
 

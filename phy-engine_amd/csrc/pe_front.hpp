@@ -884,9 +884,23 @@ namespace pe
             for(int i = t0; i < u; i += T) vs[i] = g[p + i];
         }
         double* Lg = fac + V.f_lptr[s];
+        // What later phases read: the backward pass needs U11 (upper triangle of the top p x p block of the L panel) and U12;
+        // the sub-diagonal block L21 is read by a separate forward pass only, i.e. when the factors of a linear circuit are
+        // reused -- with the fused forward substitution of a non-linear circuit nobody reads it again: not written at all.
+        bool const need_l21 = !fuse || V.keep_l21;
+        if(!need_l21)
+        {
+            float const rpp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * p; idx += T)
+            {
+                int const k = fdiv(idx, rpp), i = idx - k * p;
+                Lg[i + k * m] = Lp[i + k * m];
+            }
+        }
         if(full)
         {
-            for(int i = t0; i < m * p; i += T) Lg[i] = lds[i];
+            if(need_l21)
+                for(int i = t0; i < m * p; i += T) Lg[i] = lds[i];
             float const rp = 1.0f / static_cast<float>(p);
             for(int idx = t0; idx < p * u; idx += T)
             {
@@ -895,7 +909,7 @@ namespace pe
             }
         }
         else
-            for(int i = t0; i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
+            for(int i = t0 + (need_l21 ? 0 : m * p); i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
         tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
         if(profile && V.prof && t0 == 0)
         {
