@@ -91,6 +91,44 @@ def cpu_baseline(deck, dt, nonlinear, budget_steps):
             "sample": f"{n} TR steps of instance seed=1, oracle/pe_oracle.py (scipy SuperLU, refactor every solve), 1 thread"}
 
 
+def cpu_baseline_all_cores(W, dt, nonlinear, budget_steps, pe):
+    """the sweep on the CPU is one circuit per thread on all host cores -- one reference process per core,
+    instance seeds 1..cores, started together; aggregate = sum of the per-process steps / the slowest process's wall time.
+    Reported next to the 1-core baseline (an extra object, never the measured path)."""
+    import concurrent.futures as cf
+    import tempfile
+    drv = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    if not os.path.exists(drv):
+        return None
+    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for k in range(cores):
+            dp = os.path.join(tmp, f"i{k}.deck")
+            pe.deck.rc_mesh(W, W, k + 1, nonlinear).write(dp)
+            paths.append(dp)
+
+        def run(dp):
+            t0 = time.time()
+            out = subprocess.run([drv, dp, "--bench", "--dt", repr(dt), "--steps", str(budget_steps), "--warmup", "1"], capture_output=True, text=True,
+                                 timeout=900)
+            el = time.time() - t0
+            return (json.loads(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 else None), el
+
+        t0 = time.time()
+        with cf.ThreadPoolExecutor(max_workers=cores) as ex:
+            res = list(ex.map(run, paths))
+        wall = time.time() - t0
+    ok = [r for r, _ in res if r]
+    if len(ok) != cores:
+        return None
+    # each process times its own TR loop (netlist build / warm-up excluded): aggregate over the slowest one's loop time
+    loop_s = max(budget_steps / r["steps_per_s"] for r in ok)
+    return {"value": cores * budget_steps / loop_s, "unit": "instance-steps/s", "cores": cores, "kind": "reference",
+            "newton_iters_per_s": sum(r["newton_iters_per_s"] / r["steps_per_s"] for r in ok) * budget_steps / loop_s,
+            "sample": f"{cores} reference processes in parallel (one per host core), {budget_steps} TR steps each, seeds 1..{cores}; wall incl. start-up {wall:.1f} s"}
+
+
 def single_circuit_numbers(pe, W, dt, device):
     """One M10k instance (no batch): NL and linear, full refactorisation per solve like the reference; and the linear
     circuit with the factors reused while dt is unchanged (legitimate for a linear circuit, SURVEY.md 8d -- flagged)."""
@@ -242,6 +280,10 @@ def main():
             try:
                 line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)
                 line["speedup_vs_cpu_1core"] = line["value"] / line["cpu_baseline"]["value"]
+                allc = cpu_baseline_all_cores(W, dt, nonlinear, max(10, args.cpu_steps // 3), pe)
+                if allc:
+                    line["cpu_baseline_all_cores"] = allc
+                    line["speedup_vs_cpu_all_cores"] = line["value"] / allc["value"]
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU line
                 line["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
         print(json.dumps(line), flush=True)
