@@ -176,6 +176,13 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* stats);
 /* `nsteps` fixed-dt transient steps, every instance: update_tr_step -> t += dt -> Newton(solve_once) */
 int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats* stats);
 
+/* Small-signal AC at angular frequency omega [rad/s] (circult::solve_once with the models' iterate_ac hooks; one call per
+ * sweep point of run_ac_analysis, circuit.h:389-431).  Non-linear devices are stamped at their last linearisation: run
+ * pe_hip_analyze_dc(PE_HIP_MODE_OP) first, as the reference's AC / ACOP cases do (circuit.h:192-232).  The complex system
+ * is solved in real-equivalent form [Ar -Ai; Ai Ar] by the same kernels.  pe_hip_get_solution_ac returns the phasors. */
+int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* stats);
+int pe_hip_get_solution_ac(pe_hip_engine* h, int first_instance, int count, double* re, double* im);
+
 /* x = [node voltages ; branch currents], instance-major [count][rows] */
 int pe_hip_get_solution(pe_hip_engine* h, int first_instance, int count, double* x);
 int pe_hip_set_solution(pe_hip_engine* h, int first_instance, int count, const double* x);

@@ -28,8 +28,9 @@ void* create_circuit(int* elements, size_t ele_size, int* wires, size_t wires_si
                      size_t* comp_size);
 void destroy_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos);
 
-int circuit_set_analyze_type(void* circuit_ptr, uint32_t analyze_type_value); /* 0 OP, 1 DC, 4 TR, 5 TROP */
+int circuit_set_analyze_type(void* circuit_ptr, uint32_t analyze_type_value); /* 0 OP, 1 DC, 2 AC, 3 ACOP, 4 TR, 5 TROP */
 int circuit_set_tr(void* circuit_ptr, double t_step, double t_stop);
+int circuit_set_ac_omega(void* circuit_ptr, double omega); /* single-point AC at omega [rad/s]; samples report the real parts */
 int circuit_set_temperature(void* circuit_ptr, double temp_c);
 int circuit_set_tnom(void* circuit_ptr, double tnom_c);
 int circuit_set_model_double_by_name(void* circuit_ptr, size_t vec_pos, size_t chunk_pos, char const* name, size_t name_size, double value);

@@ -253,7 +253,7 @@ int main(int argc, char** argv)
         return 2;
     }
     char const* deck_path = argv[1];
-    std::string analysis = "TR", out = "ref_out", snaps;
+    std::string analysis = "TR", out = "ref_out", snaps, omegas;
     double dt = 0.0, gmin = 0.0, ropen = 0.0;
     long steps = 0, warmup = 1;
     bool bench = false, dump_mna = false, check_analyze = false;
@@ -268,6 +268,7 @@ int main(int argc, char** argv)
         else if(a == "--gmin") gmin = std::strtod(next(), nullptr);
         else if(a == "--ropen") ropen = std::strtod(next(), nullptr);
         else if(a == "--snap") snaps = next();
+        else if(a == "--omegas") omegas = next();
         else if(a == "--out") out = next();
         else if(a == "--bench") bench = true;
         else if(a == "--dump-mna") dump_mna = true;
@@ -290,6 +291,8 @@ int main(int argc, char** argv)
     if(analysis == "DC") at = pe::analyze_type::DC;
     else if(analysis == "OP") at = pe::analyze_type::OP;
     else if(analysis == "TROP") at = pe::analyze_type::TROP;
+    else if(analysis == "AC") at = pe::analyze_type::AC;
+    else if(analysis == "ACOP") at = pe::analyze_type::ACOP;
 
     pe::circult c{};
     c.set_analyze_type(at);
@@ -355,6 +358,37 @@ int main(int argc, char** argv)
     std::vector<int> newton_per_step;
     int fail_step = -1;
 
+    if(at == pe::analyze_type::AC || at == pe::analyze_type::ACOP)
+    {
+        // the reference's own analyze() per frequency point (prepare; OP solve when non-linear / ACOP; AC solve_once):
+        // snapshot = [Re x ; Im x]
+        std::istringstream ss(omegas);
+        std::string t;
+        long idx = 0;
+        while(std::getline(ss, t, ','))
+        {
+            c.analyzer_setting.ac.sweep = pe::analyzer::AC::sweep_type::single;
+            c.analyzer_setting.ac.omega = std::strtod(t.c_str(), nullptr);
+            bool const ok = c.analyze();
+            newton_per_step.push_back(ok ? 1 : -1);
+            if(!ok)
+            {
+                fail_step = static_cast<int>(idx);
+                break;
+            }
+            auto const xc = c.capture_solution_vector();
+            std::vector<double> x(2 * xc.size());
+            for(size_t i = 0; i < xc.size(); ++i)
+            {
+                x[i] = xc[i].real();
+                x[xc.size() + i] = xc[i].imag();
+            }
+            snap_x.push_back(std::move(x));
+            snap_at.push_back(idx++);
+        }
+    }
+    else
+    {
     c.analyzer_setting.tr.t_step = dt;
     c.analyzer_setting.tr.t_stop = dt * static_cast<double>(steps);
     c.prepare();
@@ -400,6 +434,7 @@ int main(int argc, char** argv)
                 snap_at.push_back(s);
             }
         }
+    }
     }
 
     size_t const rows = c.node_counter + c.branch_counter;

@@ -346,6 +346,16 @@ int circuit_set_analyze_type(void* circuit_ptr, uint32_t v)
     return 0;
 }
 
+// dll_api.h:175: single-point AC at omega [rad/s]
+int circuit_set_ac_omega(void* circuit_ptr, double omega)
+{
+    if(!circuit_ptr) return 1;
+    auto& ac = static_cast<pe::circult*>(circuit_ptr)->get_analyze_setting().ac;
+    ac.sweep = pe::analyzer::AC::sweep_type::single;
+    ac.omega = omega;
+    return 0;
+}
+
 int circuit_set_tr(void* circuit_ptr, double t_step, double t_stop)
 {
     if(!circuit_ptr)

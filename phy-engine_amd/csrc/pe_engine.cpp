@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/pe_hip.h"
+#include "pe_ac.hpp"
 #include "pe_circuit.hpp"
 #include "pe_device.hpp"
 #include "pe_kernels.hpp"
@@ -94,6 +95,19 @@ struct pe_hip_engine
     double fact_dt{};
     double analyze_ms{};
 
+    // small-signal AC: a second engine holding the real-equivalent 2N system (pe_ac.hpp), built on first use
+    struct Ac
+    {
+        pe_hip_engine* eng{};
+        pe::AcCircuit circ;
+        bool built{};
+        double sym_omega{-1.0};  // frequency whose values the pivot matching of the current symbolic analysis saw
+        std::vector<int> b_ptr0, b_src0;  // right-hand-side lists of the AC system (the device copy reads one slot per row)
+        int rhs0{};                       // first of the 2N right-hand-side slots of the AC value vector
+        std::vector<double> x;            // refined solution [batch][2N]
+    } ac;
+    std::vector<double> sym_values_override;  // representative |A| values for the row matching (AC engine)
+
     // solve_csr_real seam (separate small state)
     struct Csr
     {
@@ -117,6 +131,8 @@ struct pe_hip_engine
 
 namespace
 {
+    int finish_load(pe_hip_engine* h);
+
     int fail(pe_hip_engine* h, int code, std::string msg)
     {
         h->err = std::move(msg);
@@ -275,7 +291,9 @@ namespace
         if(h->sym_class == cls) return PE_HIP_OK;
         auto const t0 = clk::now();
         std::vector<double> av;
-        pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
+        if(!h->sym_values_override.empty()) av = h->sym_values_override;
+        else
+            pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
         pe::SymbolicOptions so = symbolic_options(h, h->hc.batch, h->hc.rows);
         for(int attempt = 0; attempt < 2; ++attempt)
         {
@@ -592,6 +610,7 @@ int pe_hip_create(int device, pe_hip_engine** out)
 void pe_hip_destroy(pe_hip_engine* h)
 {
     if(!h) return;
+    if(h->ac.eng) pe_hip_destroy(h->ac.eng);
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     h->circ_pool.release();
@@ -670,9 +689,24 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->fact_valid = false;
     h->circ_pool.release();
     h->sym_pool.release();
+    if(h->ac.eng)
+    {
+        pe_hip_destroy(h->ac.eng);
+        h->ac = pe_hip_engine::Ac{};
+    }
     if(!pe::build_circuit(n_nodes, n_branches, batch, n_tables, tables, static_cast<int>(h->drv_node.size()), h->drv_node.data(),
                           h->drv_volt.data(), h->hc))
         return fail(h, PE_HIP_ERR_ARG, "load_circuit: " + h->hc.error);
+    return finish_load(h);
+}
+
+}  // extern "C"
+
+namespace
+{
+// device side of a load: uploads h->hc (topology, contribution lists, parameters) and allocates the per-instance state
+int finish_load(pe_hip_engine* h)
+{
     auto const& hc = h->hc;
     pe::DevView V{};
     V.rows = hc.rows;
@@ -773,6 +807,9 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->loaded = true;
     return PE_HIP_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
 {
@@ -1206,6 +1243,160 @@ int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8)
     if(!h || !h->loaded || !ticks8 || instance < 0 || instance >= h->hc.batch) return PE_HIP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(ticks8, h->V.prof + static_cast<size_t>(instance) * pe::PE_PROF, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+/* Small-signal AC at angular frequency omega (circult::solve_once with iterate_ac, run once per sweep point by
+ * run_ac_analysis, circuit.h:389-431): complex MNA system of the devices' AC stamps, non-linear devices at their LAST
+ * linearisation (run pe_hip_analyze_dc(OP) first, as circuit.h:196-209 / the ACOP case do), solved in real-equivalent form. */
+int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
+{
+    if(!h || !h->loaded) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if(st) std::memset(st, 0, sizeof(*st));
+    auto& hc = h->hc;
+    if(hc.rows == 0) return PE_HIP_OK;
+    auto& A = h->ac;
+    if(!A.built)
+    {
+        if(!pe::build_ac_circuit(hc, A.circ)) return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: could not build the AC system");
+        if(pe_hip_create(h->device, &A.eng) != PE_HIP_OK) return fail(h, PE_HIP_ERR_NO_DEVICE, "analyze_ac: " + std::string(pe_hip_last_error(nullptr)));
+        // The right-hand side of the device copy comes from one value slot per row: the host evaluates the sources' lists
+        // and, for the refinement steps below, writes residuals there.
+        {
+            auto& c = A.circ.hc;
+            A.b_ptr0 = c.b_ptr;
+            A.b_src0 = c.b_src;
+            A.rhs0 = c.dv_len;
+            c.dv_len += c.rows;
+            c.b_ptr.resize(c.rows + 1);
+            c.b_src.resize(c.rows);
+            for(int r = 0; r <= c.rows; ++r) c.b_ptr[r] = r;
+            for(int r = 0; r < c.rows; ++r) c.b_src[r] = (A.rhs0 + r) << 1;
+        }
+        A.eng->opt = h->opt;
+        A.eng->hc = A.circ.hc;
+        int const rc = finish_load(A.eng);
+        if(rc != PE_HIP_OK) return fail(h, rc, "analyze_ac: " + A.eng->err);
+        A.built = true;
+        A.sym_omega = -1.0;
+    }
+    int const B = hc.batch;
+    // the linearisation the small-signal stamps refer to
+    pe::AcOperatingPoint op;
+    op.d_geq.resize(static_cast<size_t>(B) * hc.nD());
+    op.dv.resize(static_cast<size_t>(B) * hc.dv_len);
+    op.rl_engaged.resize(static_cast<size_t>(B) * hc.nRl());
+    if(!op.d_geq.empty()) HIPCHK(h, hipMemcpy(op.d_geq.data(), h->V.d_geq, op.d_geq.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if(!op.dv.empty()) HIPCHK(h, hipMemcpy(op.dv.data(), h->V.dv, op.dv.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if(!op.rl_engaged.empty()) HIPCHK(h, hipMemcpy(op.rl_engaged.data(), h->V.rl_engaged, op.rl_engaged.size() * sizeof(int), hipMemcpyDeviceToHost));
+    auto const& ah = A.circ.hc;
+    std::vector<double> dv(static_cast<size_t>(B) * ah.dv_len);
+    for(int b = 0; b < B; ++b) pe::fill_ac_values(hc, A.circ, op, b, omega, h->opt.g_min, r_open_of(h), &dv[static_cast<size_t>(b) * ah.dv_len]);
+    // The pivot order is static (row matching + ordering on representative values): it is (re)made on the values of
+    // instance 0 at this frequency when there is none yet, when omega moved more than a decade away from the one it was made
+    // for (reactive entries scale with omega), or when a solve with a stale order hits a bad pivot.
+    auto analyse_here = [&]()
+    {
+        int const nnz = static_cast<int>(ah.ci.size());
+        A.eng->sym_values_override.assign(nnz, 0.0);
+        for(int s = 0; s < nnz; ++s)
+        {
+            double acc = 0.0;
+            for(int e = ah.a_ptr[s]; e < ah.a_ptr[s + 1]; ++e)
+            {
+                double const v = dv[ah.a_src[e] >> 1];
+                acc = (ah.a_src[e] & 1) ? acc - v : acc + v;
+            }
+            A.eng->sym_values_override[s] = acc;
+        }
+        A.eng->sym_class = -1;
+        A.sym_omega = omega;
+    };
+    bool const stale = A.sym_omega < 0.0 || (omega == 0.0) != (A.sym_omega == 0.0) ||
+                       (omega != 0.0 && (omega > 10.0 * A.sym_omega || omega < 0.1 * A.sym_omega));
+    if(stale) analyse_here();
+    // host copies of every instance's matrix values and right-hand side (for the residuals of the refinement)
+    int const R2 = ah.rows, nnz2 = static_cast<int>(ah.ci.size());
+    std::vector<double> aval(static_cast<size_t>(B) * nnz2), rhs(static_cast<size_t>(B) * R2);
+    auto gather = [&](int const* ptr, int const* src, double const* d, int s)
+    {
+        double acc = 0.0;
+        for(int e = ptr[s]; e < ptr[s + 1]; ++e) acc = (src[e] & 1) ? acc - d[src[e] >> 1] : acc + d[src[e] >> 1];
+        return acc;
+    };
+    for(int b = 0; b < B; ++b)
+    {
+        double* d = &dv[static_cast<size_t>(b) * ah.dv_len];
+        for(int s = 0; s < nnz2; ++s) aval[static_cast<size_t>(b) * nnz2 + s] = gather(ah.a_ptr.data(), ah.a_src.data(), d, s);
+        for(int r = 0; r < R2; ++r) d[A.rhs0 + r] = rhs[static_cast<size_t>(b) * R2 + r] = gather(A.b_ptr0.data(), A.b_src0.data(), d, r);
+    }
+    auto solve = [&](std::vector<double>& out) -> int
+    {
+        // every AC point is an independent linear solve: no sticky failure state, no history
+        HIPCHK(h, hipMemcpy(A.eng->V.dv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemset(A.eng->V.status, 0, static_cast<size_t>(B) * sizeof(int)));
+        int const rc = pe_hip_analyze_dc(A.eng, PE_HIP_MODE_DC, st);
+        if(rc != PE_HIP_OK) return rc;
+        out.resize(static_cast<size_t>(B) * R2);
+        return pe_hip_get_solution(A.eng, 0, B, out.data());
+    };
+    int rc = solve(A.x);
+    if(rc == PE_HIP_ERR_SINGULAR && A.sym_omega != omega)
+    {
+        analyse_here();
+        rc = solve(A.x);
+    }
+    if(rc != PE_HIP_OK) return fail(h, rc, "analyze_ac: " + A.eng->err);
+    // Iterative refinement (the pivot order is static and the real-equivalent form separates the two halves of a complex
+    // pivot: entries like r_open = 1e12 next to j omega C leave errors far above rounding): r = b - A x on the host in fp64,
+    // A dx = r with the same pivot order, x += dx; at most three rounds, stops once the residual is at rounding level.
+    std::vector<double> dx;
+    for(int round = 0; round < 3; ++round)
+    {
+        double worst = 0.0;
+        for(int b = 0; b < B; ++b)
+        {
+            double const* av = &aval[static_cast<size_t>(b) * nnz2];
+            double const* xb = &A.x[static_cast<size_t>(b) * R2];
+            double* d = &dv[static_cast<size_t>(b) * ah.dv_len];
+            double bn = 0.0, rn = 0.0;
+            for(int r = 0; r < R2; ++r)
+            {
+                double acc = rhs[static_cast<size_t>(b) * R2 + r], mag = std::fabs(acc);
+                for(int e = ah.rp[r]; e < ah.rp[r + 1]; ++e)
+                {
+                    double const t = av[e] * xb[ah.ci[e]];
+                    acc -= t;
+                    mag += std::fabs(t);
+                }
+                d[A.rhs0 + r] = acc;
+                rn = std::max(rn, std::fabs(acc) / (mag > 0.0 ? mag : 1.0));  // componentwise backward error
+                bn = std::max(bn, mag);
+            }
+            (void)bn;
+            worst = std::max(worst, rn);
+        }
+        if(!(worst > 4.0e-16)) break;
+        rc = solve(dx);
+        if(rc != PE_HIP_OK) return fail(h, rc, "analyze_ac (refinement): " + A.eng->err);
+        for(size_t i = 0; i < A.x.size(); ++i) A.x[i] += dx[i];
+    }
+    return PE_HIP_OK;
+}
+
+/* complex solution of the last pe_hip_analyze_ac: re / im [count][rows] (node voltage and branch current phasors) */
+int pe_hip_get_solution_ac(pe_hip_engine* h, int first, int count, double* re, double* im)
+{
+    if(!h || !h->loaded || !h->ac.built || !re || !im || first < 0 || count < 0 || first + count > h->hc.batch) return PE_HIP_ERR_ARG;
+    int const N = h->hc.rows;
+    if(h->ac.x.size() != static_cast<size_t>(h->hc.batch) * 2 * N) return fail(h, PE_HIP_ERR_ARG, "get_solution_ac: no AC solution yet");
+    for(int b = 0; b < count; ++b)
+    {
+        double const* x2 = &h->ac.x[static_cast<size_t>(first + b) * 2 * N];
+        std::memcpy(re + static_cast<size_t>(b) * N, x2, N * sizeof(double));
+        std::memcpy(im + static_cast<size_t>(b) * N, x2 + N, N * sizeof(double));
+    }
     return PE_HIP_OK;
 }
 

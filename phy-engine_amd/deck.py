@@ -569,3 +569,65 @@ def relay_ramp() -> Deck:
     d.add("RELAY", (3, 0, 1, 2), 5.0, 3.0)
     d.add("R", (3, 0), 1e4)
     return d
+
+
+# --------------------------------------------------------------------------------------------
+# small-signal AC decks
+# --------------------------------------------------------------------------------------------
+def ac_rc_lowpass() -> Deck:
+    """test/0012.ac/ac_omega.cpp: VAC 1 V - 1 kOhm - 1 uF: |vout| = 1/sqrt(2) at omega = 1/(R C) = 1000 rad/s."""
+    d = Deck()
+    d.n_nodes = 2
+    d.add("VAC", (1, 0), 1.0, 1000.0, 0.0)
+    d.add("R", (1, 2), 1000.0)
+    d.add("C", (2, 0), 1e-6)
+    return d
+
+
+def ac_rlc_diode() -> Deck:
+    """Series L into R || C with a forward-biased tt-diode to a 0.7 V bias source (ACOP: diode geq and tt geq from the OP)."""
+    d = Deck()
+    d.n_nodes = 3
+    d.add("VAC", (1, 0), 1.0, 1e4, 0.3)
+    d.add("VDC", (3, 0), 0.7)
+    d.add("L", (1, 2), 1e-3)
+    d.add("R", (2, 0), 50.0)
+    d.add("C", (2, 0), 1e-6)
+    d.add("D", (3, 2), 1e-14, 1.0, 0.0, 2.0, 27.0, 1e-3, 40.0, 1.0, 1.0, 1e-8)
+    return d
+
+
+def ac_linear_mix() -> Deck:
+    """IAC + coupled inductors + transformer + VCVS / VCCS / CCCS + closed and open switches, all linear."""
+    d = Deck()
+    d.n_nodes = 8
+    d.add("IAC", (0, 1), 1e-3, 2.0 * math.pi * 1e3, 0.4)
+    d.add("R", (1, 0), 1000.0)
+    d.add("C", (1, 2), 1e-7)
+    d.add("KL", (2, 0, 3, 0), 1e-3, 4e-3, 0.8)
+    d.add("R", (3, 0), 200.0)
+    d.add("VCVS", (4, 0, 3, 0), 2.5)
+    d.add("R", (4, 5), 100.0)
+    d.add("XFMR", (5, 0, 6, 0), 2.0)
+    d.add("SW", (6, 7), 1.0)
+    d.add("R", (7, 0), 75.0)
+    d.add("C", (7, 0), 2e-7)
+    d.add("VCCS", (8, 0, 7, 0), 1e-3)
+    d.add("R", (8, 0), 1e3)
+    d.add("SW", (8, 1), 0.0)
+    return d
+
+
+def ac_nmos_amp() -> Deck:
+    """Common-source NMOS stage (saturation at the OP) driven through a coupling capacitor: gm / gds small-signal stamps."""
+    d = Deck()
+    d.n_nodes = 5
+    d.add("VDC", (1, 0), 5.0)
+    d.add("VDC", (2, 0), 2.0)
+    d.add("R", (2, 3), 1e5)
+    d.add("VAC", (4, 0), 0.01, 2.0 * math.pi * 1e4, 0.0)
+    d.add("C", (4, 3), 1e-6)
+    d.add("R", (1, 5), 2000.0)
+    d.add("NMOS", (5, 3, 0), 2e-3, 0.02, 1.0)
+    d.add("C", (5, 0), 1e-9)
+    return d

@@ -26,7 +26,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
-    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_set_time",
+    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_set_time",
 ]
 
 
@@ -318,6 +318,22 @@ class Engine:
         self._chk(fn(self._h, instance, t.ctypes.data_as(C.POINTER(C.c_longlong))))
         names = ["eval_stamp", "lu_wave", "lu_coop", "forward", "newton", "backward", "coop_asm", "coop_piv"]
         return {n: float(t[i]) / 100.0 for i, n in enumerate(names)}
+
+    def analyze_ac(self, omega, check=True):
+        """Small-signal AC at `omega` rad/s; returns the complex solution [batch][rows]."""
+        st = RunStats()
+        fn = lib().pe_hip_analyze_ac
+        fn.argtypes = [C.c_void_p, C.c_double, C.POINTER(RunStats)]
+        rc = fn(self._h, float(omega), C.byref(st))
+        if check:
+            self._chk(rc)
+        re = np.empty((self.batch, self.rows))
+        im = np.empty((self.batch, self.rows))
+        if rc == 0:
+            g = lib().pe_hip_get_solution_ac
+            g.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            self._chk(g(self._h, 0, self.batch, _dp(re), _dp(im)))
+        return re + 1j * im, rc
 
     def phase_clocks_coop(self, instance=0):
         """Per-layout breakdown of the cooperative fronts (see pe_hip_get_phase_clocks_ex), microseconds / counts."""

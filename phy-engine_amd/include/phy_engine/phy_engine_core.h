@@ -16,6 +16,7 @@
 // which describes it as rows of the device tables of include/pe_hip.h.  A netlist containing a model without that hook
 // is rejected by analyze() (returns false, message in circult::last_error) -- there is no CPU numeric path.
 #pragma once
+#include <cmath>
 #include <complex>
 #include <concepts>
 #include <cstddef>
@@ -69,10 +70,25 @@ namespace phy_engine
         struct DC
         {
         };
+        struct AC  // circuits/analyzer/AC.h
+        {
+            enum class sweep_type : ::std::uint_fast8_t
+            {
+                single = 0,
+                linear = 1,
+                log = 2,
+            };
+            sweep_type sweep{sweep_type::single};
+            double omega{};        // rad/s; updated per point in sweep mode
+            double omega_start{};
+            double omega_stop{};
+            ::std::size_t points{};
+        };
         struct analyzer_storage_t
         {
             TR tr{};
             DC dc{};
+            AC ac{};
         };
     }  // namespace analyzer
 
@@ -802,8 +818,103 @@ namespace phy_engine
                     return solve();
                 case analyze_type::TR: return run_tr(false);
                 case analyze_type::TROP: return run_tr(true);
-                default: last_error = "AC / ACOP analysis is outside the MI355X hot path (SURVEY.md 8f)"; return false;
+                case analyze_type::AC:  // circuit.h:192-212: operating point first when a non-linear device needs a linearisation
+                case analyze_type::ACOP:  // circuit.h:213-232: always
+                {
+                    if(!prepare()) return false;
+                    ac_sweep_results.clear();
+                    if(at == analyze_type::ACOP || has_nonlinear_device())
+                    {
+                        auto const saved = at;
+                        at = analyze_type::OP;
+                        bool const ok = solve();
+                        at = saved;
+                        if(!ok) return false;
+                    }
+                    return run_ac_analysis();
+                }
+                default: return false;
             }
+        }
+
+        // circuit.h:70-82, 173-177
+        struct ac_sweep_point
+        {
+            double omega{};
+            ::std::vector<::std::complex<double>> x{};  // node voltages ; branch currents
+        };
+        ::std::vector<ac_sweep_point> ac_sweep_results{};
+        auto& get_ac_sweep_results() noexcept { return ac_sweep_results; }
+        void clear_ac_sweep_results() noexcept { ac_sweep_results.clear(); }
+
+        // circuit.h:433-445
+        [[nodiscard]] bool has_nonlinear_device() const noexcept
+        {
+            for(auto const& blk: nl.models)
+                for(auto* c = blk.begin; c != blk.curr; ++c)
+                    if(c->type == ::phy_engine::model::model_type::normal && c->ptr &&
+                       c->ptr->get_device_type() == ::phy_engine::model::model_device_type::non_linear)
+                        return true;
+            return false;
+        }
+
+        // circuit.h:376-388
+        [[nodiscard]] ::std::vector<::std::complex<double>> capture_solution_vector() const
+        {
+            ::std::vector<::std::complex<double>> x(node_counter + branch_counter);
+            for(auto const* n: size_t_to_node_p) x[n->node_index] = n->node_information.an.voltage;
+            for(auto const* b: size_t_to_branch_p) x[node_counter + b->index] = b->current;
+            return x;
+        }
+
+        // circuit.h:389-431: single point, linear or logarithmic sweep of omega; every point is one AC solve on the device
+        [[nodiscard]] bool run_ac_analysis() noexcept
+        {
+            auto& ac = analyzer_setting.ac;
+            using sweep_t = ::phy_engine::analyzer::AC::sweep_type;
+            if(ac.sweep == sweep_t::single || ac.points <= 1) return solve_ac_point(ac.omega);
+            ac_sweep_results.clear();
+            if(ac.sweep == sweep_t::linear)
+            {
+                double const step = (ac.omega_stop - ac.omega_start) / static_cast<double>(ac.points - 1);
+                for(::std::size_t i = 0; i < ac.points; ++i)
+                {
+                    ac.omega = ac.omega_start + step * static_cast<double>(i);
+                    if(!solve_ac_point(ac.omega)) return false;
+                    ac_sweep_results.push_back({ac.omega, capture_solution_vector()});
+                }
+                return true;
+            }
+            if(ac.sweep == sweep_t::log)
+            {
+                if(ac.omega_start <= 0.0 || ac.omega_stop <= 0.0) return false;
+                double const ratio = ::std::pow(ac.omega_stop / ac.omega_start, 1.0 / static_cast<double>(ac.points - 1));
+                double omega = ac.omega_start;
+                for(::std::size_t i = 0; i < ac.points; ++i)
+                {
+                    ac.omega = omega;
+                    if(!solve_ac_point(ac.omega)) return false;
+                    ac_sweep_results.push_back({ac.omega, capture_solution_vector()});
+                    omega *= ratio;
+                }
+                return true;
+            }
+            return solve_ac_point(ac.omega);
+        }
+
+        // one AC solve (solve_once with iterate_ac): phasors scattered into the nodes / branches as complex values
+        bool solve_ac_point(double omega) noexcept
+        {
+            if(!gpu_ || !loaded_) return false;
+            ::std::size_t const rows = node_counter + branch_counter;
+            if(!rows) return true;
+            if(pe_hip_analyze_ac(gpu_, omega, &last_stats) != PE_HIP_OK) return gpu_fail();
+            ::std::vector<double> re(rows), im(rows);
+            if(pe_hip_get_solution_ac(gpu_, 0, 1, re.data(), im.data()) != PE_HIP_OK) return gpu_fail();
+            for(auto* n: size_t_to_node_p) n->node_information.an.voltage = {re[n->node_index], im[n->node_index]};
+            nl.ground_node.node_information.an.voltage = {};
+            for(auto* b: size_t_to_branch_p) b->current = {re[node_counter + b->index], im[node_counter + b->index]};
+            return true;
         }
 
         // circuit.h:298-354: one digital tick.  Runs on the host by design (integer / enum event logic);

@@ -84,6 +84,15 @@ CASES["center_tap_ratio"] = (("center_tap_ratio", {}), "DC", 0.0, 0, 0.0, "", Tr
 CASES["relay_ramp_tr"] = (("relay_ramp", {}), "TR", 1e-4, 200, 0.0, "1,30,62,63,64,70,100,130,137,138,139,150,200", True)
 
 
+# small-signal AC: snapshots are [Re x ; Im x] per frequency point
+AC_OMEGAS = {"ac_rc_lowpass": [10.0, 1000.0, 1e5], "ac_rlc_diode_acop": [0.0, 1e3, 2e4, 1e6], "ac_linear_mix": [100.0, 6283.185307179586, 1e5],
+             "ac_nmos_amp": [1e2, 6.283185307179586e4, 1e7]}
+CASES["ac_rc_lowpass"] = (("ac_rc_lowpass", {}), "AC", 0.0, 0, 0.0, "", True)
+CASES["ac_rlc_diode_acop"] = (("ac_rlc_diode", {}), "ACOP", 0.0, 0, 0.0, "", True)
+CASES["ac_linear_mix"] = (("ac_linear_mix", {}), "AC", 0.0, 0, 0.0, "", True)
+CASES["ac_nmos_amp"] = (("ac_nmos_amp", {}), "AC", 0.0, 0, 0.0, "", True)
+
+
 def tt_diode_deck():
     """test/0004.solver/pn_junction_tt_tr.cpp: VDC 0.7 + VAC 0.1 (omega*dt = pi/2) across a tt=1e-9 diode."""
     import math
@@ -111,13 +120,17 @@ def run_case(name):
             cmd += ["--dt", repr(dt), "--steps", str(steps), "--snap", snaps]
         if name in R_OPEN:
             cmd += ["--ropen", repr(R_OPEN[name])]
-        if d.rows <= 2000:
+        if name in AC_OMEGAS:
+            cmd += ["--omegas", ",".join(repr(w) for w in AC_OMEGAS[name])]
+        if d.rows <= 2000 and analysis not in ("AC", "ACOP"):
             cmd += ["--check-analyze"]
         subprocess.run(cmd, check=True)
         meta = json.load(open(out + ".json"))
         meta["recipe"] = {"fn": fn, "kwargs": kw}
         if name in R_OPEN:
             meta["r_open"] = R_OPEN[name]
+        if name in AC_OMEGAS:
+            meta["omegas"] = AC_OMEGAS[name]
         meta["generator"] = "scripts/make_golden.py via oracle/_ref/ref_driver (real reference)"
         json.dump(meta, open(os.path.join(GOLD, name + ".json"), "w"))
         os.replace(out + ".bin", os.path.join(GOLD, name + ".bin"))

@@ -18,7 +18,8 @@ MODES = {"OP": pe.ffi.MODE_OP, "DC": pe.ffi.MODE_DC, "TROP": pe.ffi.MODE_TROP}
 
 def golden(name):
     meta = json.load(open(os.path.join(GOLD, name + ".json")))
-    x = np.fromfile(os.path.join(GOLD, name + ".bin")).reshape(-1, meta["rows"]) if meta["rows"] else np.zeros((0, 0))
+    width = meta["rows"] * (2 if meta["analysis"] in ("AC", "ACOP") else 1)
+    x = np.fromfile(os.path.join(GOLD, name + ".bin")).reshape(-1, width) if meta["rows"] else np.zeros((0, 0))
     dp = os.path.join(GOLD, name + ".deck")
     if os.path.exists(dp):
         deck = pe.deck.Deck.read(dp)
@@ -65,3 +66,24 @@ def run_engine_case(eng, meta, deck, batch=1, overrides=None):
 def max_err(a, b, atol, rtol):
     """max over entries of |a-b| / (atol + rtol*|b|): <= 1 passes."""
     return float(np.max(np.abs(a - b) / (atol + rtol * np.abs(b)))) if a.size else 0.0
+
+
+def run_ac_case(eng, meta, deck):
+    """AC / ACOP golden: the operating point first when the circuit is non-linear (or ACOP), then one AC solve per omega.
+    Returns complex snapshots [n_omega][rows] of instance 0."""
+    eng.set_options(g_min=meta["gmin"], r_open=meta.get("r_open", 0.0))
+    eng.load_deck(deck)
+    eng.reset()
+    if meta["analysis"] == "ACOP" or deck.has_nonlinear():
+        eng.analyze_dc(MODES["OP"])
+    out = []
+    for w in meta["omegas"]:
+        x, rc = eng.analyze_ac(w)
+        assert rc == 0
+        out.append(x[0])
+    return np.array(out)
+
+
+def golden_complex(meta, gx):
+    n = meta["rows"]
+    return gx[:, :n] + 1j * gx[:, n:]

@@ -19,7 +19,7 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal"]  # adc_flash: checked against the golden below
+TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")

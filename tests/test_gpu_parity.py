@@ -7,7 +7,7 @@ Tolerances (fp64): linear circuits abs 1e-9 + rel 1e-7; non-linear abs 1e-6 + re
 import numpy as np
 import pytest
 
-from parity_common import golden, max_err, pe, run_engine_case
+from parity_common import golden, golden_complex, max_err, pe, run_ac_case, run_engine_case
 
 pytestmark = pytest.mark.gpu
 
@@ -333,3 +333,25 @@ def test_reuse_factor_multi_workgroup():
         out.append(e.solution()[0])
     e.close()
     assert np.max(np.abs(out[0] - out[1])) <= 1e-13
+
+
+# ---- small-signal AC (complex system solved in real-equivalent form by the same kernels) ----------
+@pytest.mark.parametrize("name", ["ac_rc_lowpass", "ac_rlc_diode_acop", "ac_linear_mix", "ac_nmos_amp"])
+def test_ac_golden_parity(eng, name):
+    meta, gx, deck = golden(name)
+    xs = run_ac_case(eng, meta, deck)
+    g = golden_complex(meta, gx)
+    assert xs.shape == g.shape
+    assert np.all(np.abs(xs - g) <= 1e-9 + 1e-6 * np.abs(g))
+
+
+def test_ac_sweep_batch_of_instances(eng):
+    """AC over a batch: instance b of a C sweep has its corner at omega = 1 / (R C_b); |v_out| = 1 / sqrt(2) there."""
+    d = pe.deck.ac_rc_lowpass()
+    caps = np.array([1e-6, 2e-6, 5e-7, 1e-7])
+    eng.set_options(g_min=0.0)
+    eng.load_deck(d, batch=4, overrides={"C": caps[:, None, None]})
+    eng.reset()
+    for b, c in enumerate(caps):
+        x, rc = eng.analyze_ac(1.0 / (1000.0 * c))
+        assert rc == 0 and abs(abs(x[b][1]) - 2.0 ** -0.5) < 1e-12

@@ -153,3 +153,23 @@ assert max_err(snaps[:, 0, :], gx, 1e-9, 1e-6) <= 1.0
 assert list(trace) == meta['newton_iters']
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
+@pytest.mark.parametrize("name", ["ac_rc_lowpass", "ac_rlc_diode_acop", "ac_linear_mix", "ac_nmos_amp"])
+def test_ac_real_equivalent_system_under_host_emulation(emu_lib, name):
+    """The AC path's host logic (real-equivalent 2N system, value vector per omega, operating-point hand-over) with the
+    kernels emulated; compared with the reference's complex phasors."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np
+from parity_common import *
+meta, gx, deck = golden({name!r})
+eng = pe.ffi.Engine()
+xs = run_ac_case(eng, meta, deck)
+g = golden_complex(meta, gx)
+assert xs.shape == g.shape
+assert np.all(np.abs(xs - g) <= 1e-9 + 1e-6 * np.abs(g)), np.max(np.abs(xs - g))
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)

@@ -5,7 +5,7 @@ import math
 import numpy as np
 import pytest
 
-from parity_common import golden
+from parity_common import golden, golden_complex
 
 FAST = ["rc_step", "rl_step", "rlc_series_vl", "rlc_series_vl_trop", "divider_dc", "diode_op", "pn_tt_tr", "ladder_c1", "bridge_c2",
         "mesh32_lin", "mesh32_nl", "mesh32_lin_seed3", "mesh32_nl_seed7"]
@@ -49,6 +49,28 @@ def test_oracle_unlimited_exponential_fails_like_reference(oracle_mod, name):
         else:
             assert not o.analyze_dc(meta["analysis"])
     assert o.newton_iters[0] < 0
+
+
+AC_CASES = ["ac_rc_lowpass", "ac_rlc_diode_acop", "ac_linear_mix", "ac_nmos_amp"]
+
+
+@pytest.mark.parametrize("name", AC_CASES)
+def test_oracle_ac_matches_reference_golden(oracle_mod, name):
+    """Small-signal AC: complex phasors of every node voltage / branch current per frequency point."""
+    meta, gx, deck = golden(name)
+    o = oracle_mod.Oracle(deck, g_min=meta["gmin"])
+    xs = o.analyze_ac(meta["omegas"], acop=meta["analysis"] == "ACOP")
+    g = golden_complex(meta, gx)
+    assert xs is not None and len(xs) == len(g)
+    for x, gg in zip(xs, g):
+        assert np.all(np.abs(x - gg) <= 1e-9 + 1e-7 * np.abs(gg))
+
+
+def test_known_answer_ac_lowpass(oracle_mod, pe):
+    """test/0012.ac/ac_omega.cpp: |v_out| in (0.6, 0.8) at omega = 1 / (R C) -- exactly 1 / sqrt(2)."""
+    o = oracle_mod.Oracle(pe.deck.ac_rc_lowpass())
+    x = o.analyze_ac([1000.0])[0]
+    assert abs(abs(x[1]) - 1.0 / math.sqrt(2.0)) < 1e-12
 
 
 def test_oracle_mesh100_first_steps(oracle_mod):
