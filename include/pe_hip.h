@@ -176,6 +176,13 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* stats);
 /* `nsteps` fixed-dt transient steps, every instance: update_tr_step -> t += dt -> Newton(solve_once) */
 int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats* stats);
 
+/* Checkpoint / resume of the device-resident simulation state of every instance (solution, time, companion histories,
+ * junction and relay state, counters, device values): a transient continued from a loaded checkpoint is bit-identical to an
+ * uninterrupted one.  The blob does not contain the circuit: load the same circuit (same tables, same batch) first. */
+int pe_hip_checkpoint_size(pe_hip_engine* h, size_t* bytes);
+int pe_hip_checkpoint_save(pe_hip_engine* h, void* buffer, size_t capacity);
+int pe_hip_checkpoint_load(pe_hip_engine* h, const void* buffer, size_t size);
+
 /* Small-signal AC at angular frequency omega [rad/s] (circult::solve_once with the models' iterate_ac hooks; one call per
  * sweep point of run_ac_analysis, circuit.h:389-431).  Non-linear devices are stamped at their last linearisation: run
  * pe_hip_analyze_dc(PE_HIP_MODE_OP) first, as the reference's AC / ACOP cases do (circuit.h:192-232).  The complex system

@@ -26,7 +26,7 @@ EXPORTS = [
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
-    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_set_time",
+    "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",
 ]
 
 
@@ -318,6 +318,20 @@ class Engine:
         self._chk(fn(self._h, instance, t.ctypes.data_as(C.POINTER(C.c_longlong))))
         names = ["eval_stamp", "lu_wave", "lu_coop", "forward", "newton", "backward", "coop_asm", "coop_piv"]
         return {n: float(t[i]) / 100.0 for i, n in enumerate(names)}
+
+    def checkpoint(self) -> bytes:
+        """Device-resident simulation state of every instance as one blob (pe_hip_checkpoint_save)."""
+        n = C.c_size_t()
+        lib().pe_hip_checkpoint_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        self._chk(lib().pe_hip_checkpoint_size(self._h, C.byref(n)))
+        buf = C.create_string_buffer(n.value)
+        lib().pe_hip_checkpoint_save.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        self._chk(lib().pe_hip_checkpoint_save(self._h, buf, n.value))
+        return buf.raw
+
+    def restore(self, blob: bytes):
+        lib().pe_hip_checkpoint_load.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        self._chk(lib().pe_hip_checkpoint_load(self._h, blob, len(blob)))
 
     def analyze_ac(self, omega, check=True):
         """Small-signal AC at `omega` rad/s; returns the complex solution [batch][rows]."""

@@ -355,3 +355,34 @@ def test_ac_sweep_batch_of_instances(eng):
     for b, c in enumerate(caps):
         x, rc = eng.analyze_ac(1.0 / (1000.0 * c))
         assert rc == 0 and abs(abs(x[b][1]) - 2.0 ** -0.5) < 1e-12
+
+
+def test_checkpoint_resume_is_bit_exact(eng):
+    """a transient interrupted by checkpoint -> new engine -> restore continues bit-identically
+    (non-linear mesh with diodes' limiting / transit state, a 3-instance sweep)."""
+    deck, r, c = pe.deck.rc_mesh_params(32, 32, [1, 2, 3], True)
+    ov = {"R": r[:, :, None], "C": c[:, :, None]}
+    eng.set_options(g_min=0.0)
+    eng.load_deck(deck, batch=3, overrides=ov)
+    eng.reset()
+    eng.analyze_tr(1e-10, 60)
+    want, want_state = eng.solution().copy(), eng.state()
+    eng.reset()
+    eng.analyze_tr(1e-10, 25)
+    blob = eng.checkpoint()
+    e2 = pe.ffi.Engine(device=0)
+    e2.set_options(g_min=0.0)
+    e2.load_deck(deck, batch=3, overrides=ov)
+    e2.restore(blob)
+    e2.analyze_tr(1e-10, 35)
+    got, got_state = e2.solution(), e2.state()
+    e2.close()
+    assert np.array_equal(got, want)
+    assert np.array_equal(got_state["iters"], want_state["iters"]) and np.array_equal(got_state["steps"], want_state["steps"])
+    assert np.array_equal(got_state["t"], want_state["t"])
+    # a checkpoint of another circuit is refused
+    e3 = pe.ffi.Engine(device=0)
+    e3.load_deck(pe.deck.rc_step())
+    with pytest.raises(pe.ffi.PeHipError):
+        e3.restore(blob)
+    e3.close()

@@ -173,3 +173,28 @@ assert xs.shape == g.shape
 assert np.all(np.abs(xs - g) <= 1e-9 + 1e-6 * np.abs(g)), np.max(np.abs(xs - g))
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
+def test_checkpoint_resume_under_host_emulation(emu_lib):
+    """Host logic of pe_hip_checkpoint_save / load: an interrupted transient continues bit-identically; a blob of another
+    circuit is refused."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load()
+deck, r, c = pe.deck.rc_mesh_params(8, 8, [1, 2], True)
+ov = {{"R": r[:, :, None], "C": c[:, :, None]}}
+eng = pe.ffi.Engine(); eng.set_options(g_min=0.0); eng.load_deck(deck, batch=2, overrides=ov); eng.reset()
+eng.analyze_tr(1e-10, 30); want = eng.solution().copy()
+eng.reset(); eng.analyze_tr(1e-10, 12); blob = eng.checkpoint()
+e2 = pe.ffi.Engine(); e2.set_options(g_min=0.0); e2.load_deck(deck, batch=2, overrides=ov); e2.restore(blob); e2.analyze_tr(1e-10, 18)
+assert np.array_equal(e2.solution(), want)
+e3 = pe.ffi.Engine(); e3.load_deck(pe.deck.rc_step())
+try:
+    e3.restore(blob); raise SystemExit(1)
+except pe.ffi.PeHipError:
+    pass
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
