@@ -7,9 +7,11 @@
 //   companion_update  circult::update_tr_step -> step_changed_tr_define of capacitor.h:106-128,
 //                     inductor.h:134-160, PN_junction.h:440-476
 //   eval_devices      iterate_{dc,tr,trop}_define of capacitor.h:132-155, inductor.h:164-195, VAC.h:162-179,
-//                     PN_junction.h:358-402,478-503 (vlimit :58-109, limexp :10-16)
+//                     PN_junction.h:358-402,478-503 (vlimit :58-109, limexp :10-16); IAC.h:148-160, the four generators,
+//                     coupled_inductors.h:160-246, relay.h:84-95, nmosfet.h / pmosfet.h:91-122, BJT_NPN.h / BJT_PNP.h:122-146
 //   stamp             MNA accumulation of circult::solve_once (circuit.h:1015-1110, mna.h:60-157)
-//   factor/solve      replaces Eigen SparseLU compute()+solve() (circuit.h:1516-1518)
+//   factor/solve      replaces Eigen SparseLU compute()+solve() (circuit.h:1516-1518); the forward substitution is fused
+//                     into the factorisation whenever a solve follows it (front_factor, `fuse`)
 //   newton_converged  circult::solve convergence test (circuit.h:921-948)
 #pragma once
 #include "pe_device.hpp"

@@ -5,6 +5,14 @@
 // triangular solves with the front-local vectors in LDS, Newton test -- with workgroup barriers only, no
 // inter-workgroup traffic and no host round trip inside a time step.  A Monte-Carlo sweep fills the chip with
 // independent instances (256 CUs x k workgroups); symbolic data is shared read-only and stays in L2/MALL.
+//
+// Two launch schemes share the front code of pe_front.hpp:
+//   * resident kernels k_tr_steps<MINW> / k_dc_point<MINW> / k_factor_solve: one workgroup per instance does everything
+//     (MINW = 2: <= 256 VGPRs, one 512-thread workgroup per CU; MINW = 4: 128 VGPRs, 256-thread workgroups, 4 per CU);
+//   * multi-workgroup schedule k_m2_*: one launch per phase and per top level of the assembly tree, an instance spread over
+//     n_parts workgroups + one workgroup per top front; the host drives the Newton loop from one flag word per instance
+//     (pe_engine.cpp run_m2_tr / m2_point).  Selected for few instances of a large circuit.
+// Small-signal AC runs the same kernels on the real-equivalent 2N system (pe_ac.cpp).
 #include <hip/hip_runtime.h>
 
 #include "pe_front.hpp"
