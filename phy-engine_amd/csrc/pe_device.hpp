@@ -14,7 +14,8 @@ namespace pe
     };
     // in-kernel phase clocks per instance: [0] eval+stamp, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward, [4] -,
     // [5] backward, [6] cooperative assembly, [7] cooperative block loop; then per cooperative front layout L = 0 whole-front,
-    // 1 panel+pull, 2 chain link at 8 + 6 L: assembly, block loop, Schur, store, fronts, sum of m*m
+    // 1 panel+pull, 2 chain link at 8 + 6 L: assembly, block loop, Schur, store, fronts, sum of m*m; [26..31] wave-phase time of
+    // wavefronts 0..5 of part 0
     enum : int
     {
         PE_PROF = 32
@@ -107,7 +108,7 @@ namespace pe
         // top fronts of level l: top_list[top_ptr[l] ..)  (multi-workgroup mode only)
         int const *wave_ptr, *wave_list, *coop_ptr, *coop_list, *top_ptr, *top_list;
         int n_parts, n_top_levels, n_waves;
-        int top_cnt[16];        // fronts per top level (host-side copy for the launch geometry)
+        int top_cnt[64];        // fronts per top level (host-side copy for the launch geometry)
         int* active;            // [.] multi-workgroup mode: instances still iterating
         int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)

@@ -199,7 +199,7 @@ namespace
         HIPCHK(h, pool.upload(V.top_list, S.top_list));
         V.n_parts = S.n_parts;
         V.n_top_levels = static_cast<int>(S.top_ptr.size()) - 1;
-        if(V.n_top_levels > 16) return fail(h, PE_HIP_ERR_INTERNAL, "assembly tree has more than 16 top levels");
+        if(V.n_top_levels > 64) return fail(h, PE_HIP_ERR_INTERNAL, "assembly tree has more than 64 top levels");
         for(int l = 0; l < V.n_top_levels; ++l) V.top_cnt[l] = S.top_ptr[l + 1] - S.top_ptr[l];
         V.n_waves = so.n_waves;
         V.high_occupancy = geometry_batch(batch) >= 384 ? 1 : 0;
@@ -213,7 +213,7 @@ namespace
         V.lds_sslot = so.wave_m + V.lds_wave_stage + 64;       // t[m] + staged block + partial sums of one wavefront
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
-            need = std::max(need, so.panel_doubles);
+            need = std::max(need, so.panel_doubles + so.panel_reserve);
             need = std::max(need, static_cast<long long>(so.n_waves) * V.lds_sslot);
             need = std::max(need, static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
             V.lds_doubles = static_cast<int>(need + 2);
@@ -282,6 +282,7 @@ namespace
         // large (panel-mode) fronts keep room behind the panels for the right-hand-side column (m doubles) and their
         // children's staged inverse maps
         so.panel_doubles = std::max<long long>(lds_doubles - panel_reserve, lds_doubles / 2);
+        so.panel_reserve = lds_doubles - so.panel_doubles;
         return so;
     }
 
@@ -302,9 +303,12 @@ namespace
                 h->sym_class = -1;
                 return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
             }
-            // a front larger than the reserve behind the panels: analyse again with room for its right-hand-side column
-            if(h->sym.max_m + 8 <= 384 || attempt == 1) break;
-            so = symbolic_options(h, h->hc.batch, h->hc.rows, h->sym.max_m + 72);
+            // a front larger than the reserve behind the panels: analyse again with room for its right-hand-side column;
+            // a top of the tree deeper than the launch table: fall back to one workgroup per instance (no top levels)
+            bool const too_deep = static_cast<int>(h->sym.top_ptr.size()) - 1 > 64;
+            if((h->sym.max_m + 8 <= so.panel_reserve && !too_deep) || attempt == 1) break;
+            so = symbolic_options(h, h->hc.batch, h->hc.rows, std::max(384, h->sym.max_m + 72));
+            if(too_deep) so.n_parts = 1;
         }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
         {

@@ -945,6 +945,8 @@ namespace pe
                         fail = 1;
                         break;
                     }
+                // per-wavefront time of the wave phase (load balance of the static subtree assignment), part 0, wavefronts 0..5
+                if(V.prof && part == 0 && lane == 0 && w < 6) V.prof[b * PE_PROF + 26 + w] += tm.clock() - c0;
             });
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();

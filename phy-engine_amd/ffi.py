@@ -360,6 +360,7 @@ class Engine:
         for L, name in enumerate(("whole", "panel", "chain")):
             q = t[8 + 6 * L: 14 + 6 * L]
             out[name] = {"asm": q[0] / 100.0, "piv": q[1] / 100.0, "schur": q[2] / 100.0, "store": q[3] / 100.0, "fronts": int(q[4]), "sum_m2": int(q[5])}
+        out["wave_phase_us"] = [float(v) / 100.0 for v in t[26:32]]
         return out
 
     def update_param(self, kind, index, column, values):

@@ -386,3 +386,23 @@ def test_checkpoint_resume_is_bit_exact(eng):
     with pytest.raises(pe.ffi.PeHipError):
         e3.restore(blob)
     e3.close()
+
+
+def test_large_circuit_40k_nodes(oracle_mod):
+    """200 x 200 diode mesh (40 002 rows, fronts up to 300 rows, 22 top levels): single instance (multi-workgroup schedule)
+    and a 2-instance batch against the oracle."""
+    deck = pe.deck.rc_mesh(200, 200, 1, True)
+    o = oracle_mod.Oracle(deck)
+    o.analyze_tr(1e-10, 3)
+    for batch in (1, 2):
+        e = pe.ffi.Engine(device=0)
+        e.set_options(g_min=0.0)
+        e.load_deck(deck, batch=batch)
+        e.reset()
+        st = e.analyze_tr(1e-10, 3)
+        x = e.solution()
+        assert st["newton_iters"] == batch * sum(o.newton_iters)
+        for b in range(batch):
+            assert max_err(x[b], o.x, *NL) <= 1.0
+        assert e.info()["max_front"] >= 250
+        e.close()

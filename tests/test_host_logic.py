@@ -198,3 +198,25 @@ except pe.ffi.PeHipError:
     pass
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
+def test_large_fronts_under_host_emulation(emu_lib, oracle_mod):
+    """A 200 x 200 diode mesh (40 002 rows, fronts up to 300, 22 top levels in the multi-workgroup schedule): the panel
+    layout's LDS regions (panels + right-hand-side column + staged child maps) must fit what the launch allocates.  Regression
+    test for an LDS overrun found with AddressSanitizer on the emulation build."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load(); orc = pe_load.load_oracle()
+deck = pe.deck.rc_mesh(200, 200, 1, True)
+eng = pe.ffi.Engine(); eng.set_options(g_min=0.0); eng.load_deck(deck); eng.reset()
+st = eng.analyze_tr(1e-10, 2)
+o = orc.Oracle(deck); o.analyze_tr(1e-10, 2)
+assert st['newton_iters'] == sum(o.newton_iters)
+assert np.max(np.abs(eng.solution()[0] - o.x) / (1e-6 + 1e-5 * np.abs(o.x))) <= 1.0
+i = eng.info()
+assert i['lds_bytes'] <= 163840 and i['max_front'] > 150 and i['n_top_levels'] > 16
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=600)
