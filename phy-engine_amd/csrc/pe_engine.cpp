@@ -226,7 +226,7 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
-    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve = 384)
+    pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve = 384, int force_resident = 0)
     {
         int const batch = geometry_batch(batch_in);
         pe::SymbolicOptions so{};
@@ -273,7 +273,8 @@ namespace
         so.part_cut = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_PART_CUT_X10", static_cast<int>(so.part_cut * 10.0)));
         so.wave_p = std::min(so.wave_p, so.max_pivots);
         // LDS share of one workgroup: the 128-VGPR kernels keep 16 wavefronts per CU resident (16 / n_waves workgroups)
-        int const resident = std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", batch >= 384 ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
+        int const resident =
+            force_resident > 0 ? force_resident : std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", batch >= 384 ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
         long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
         // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
         while(static_cast<long long>(so.n_waves) * so.wave_m * (so.wave_m + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
@@ -296,18 +297,24 @@ namespace
         else
             pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
         pe::SymbolicOptions so = symbolic_options(h, h->hc.batch, h->hc.rows);
-        for(int attempt = 0; attempt < 2; ++attempt)
+        for(int attempt = 0;; ++attempt)
         {
             if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
             {
                 h->sym_class = -1;
                 return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
             }
-            // a front larger than the reserve behind the panels: analyse again with room for its right-hand-side column;
-            // a top of the tree deeper than the launch table: fall back to one workgroup per instance (no top levels)
+            // A front's right-hand-side column (m doubles) must fit the reserve behind its panels, and the top of the tree the
+            // launch table.  Escalation: (1) a larger reserve; (2) the whole LDS of a CU for one workgroup; else give up loudly.
             bool const too_deep = static_cast<int>(h->sym.top_ptr.size()) - 1 > 64;
-            if((h->sym.max_m + 8 <= so.panel_reserve && !too_deep) || attempt == 1) break;
-            so = symbolic_options(h, h->hc.batch, h->hc.rows, std::max(384, h->sym.max_m + 72));
+            bool const fits = h->sym.max_m + 8 <= so.panel_reserve;
+            if(fits && !too_deep) break;
+            if(attempt == 2)
+            {
+                h->sym_class = -1;
+                return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: a front of order " + std::to_string(h->sym.max_m) + " does not fit the LDS of a CU");
+            }
+            so = symbolic_options(h, h->hc.batch, h->hc.rows, std::max(384, h->sym.max_m + 72), attempt == 1 ? 1 : 0);
             if(too_deep) so.n_parts = 1;
         }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
