@@ -406,3 +406,32 @@ def test_large_circuit_40k_nodes(oracle_mod):
             assert max_err(x[b], o.x, *NL) <= 1.0
         assert e.info()["max_front"] >= 250
         e.close()
+
+
+@pytest.mark.parametrize("geometry", [None, "1024", "500"])
+def test_dense_circuit_single_large_front(oracle_mod, geometry, monkeypatch):
+    """A complete graph of 400 resistors-nodes: ONE front of order 401, far beyond what fits LDS whole at any launch geometry
+    (panel layout with p of 8-24, long chain of links); DC against the oracle, for the three workgroup geometries."""
+    if geometry:
+        monkeypatch.setenv("PHY_ENGINE_HIP_GEOMETRY_BATCH", geometry)
+    n = 400
+    d = pe.deck.Deck()
+    d.n_nodes = n
+    rng = np.random.default_rng(1)
+    for i in range(1, n + 1):
+        for j in range(i + 1, n + 1):
+            d.add("R", (i, j), float(100.0 + 900.0 * rng.random()))
+    d.add("VDC", (1, 0), 1.0)
+    d.add("R", (n, 0), 50.0)
+    o = oracle_mod.Oracle(d)
+    assert o.analyze_dc("DC")
+    e = pe.ffi.Engine(device=0)
+    e.set_options(g_min=0.0)
+    e.load_deck(d, batch=2)
+    e.reset()
+    e.analyze_dc(pe.ffi.MODE_DC)
+    x = e.solution()
+    assert e.info()["max_front"] == n + 1
+    for b in range(2):
+        assert max_err(x[b], o.x, *LIN) <= 1.0
+    e.close()
