@@ -821,6 +821,18 @@ namespace pe
             tm.for_each_wave(
                 [&](int w, int lane, int NL)
                 {
+                    // chain link: the child's tile for the NEXT round is requested before this round's MFMA / store, so its
+                    // (global, unconditional) loads fly behind the arithmetic
+                    double const* Sch = chain ? arena + V.f_sptr[V.f_child[ch0]] : nullptr;
+                    auto chain_tile = [&](int tile)
+                    {
+                        int const tj = tile / nt, ti = tile - tj * nt;
+                        int const i0 = 16 * ti, j0 = 16 * tj;
+                        int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
+                        return tm.tile_load(Sch + (p + i0) + static_cast<long long>(p + j0) * m, m, mr, nc, lane);
+                    };
+                    auto nxt = tm.tile_zero();
+                    if(chain && w < nt * nt) nxt = chain_tile(w);
                     for(int tile = w; tile < nt * nt; tile += NW)
                     {
                         int const tj = tile / nt, ti = tile - tj * nt;
@@ -829,7 +841,10 @@ namespace pe
                         auto acc = tm.tile_zero();
                         if(full) acc = tm.tile_load(Up + p + i0 + j0 * ldu, ldu, mr, nc, lane);
                         else if(chain)
-                            acc = tm.tile_load(arena + V.f_sptr[V.f_child[ch0]] + (p + i0) + static_cast<long long>(p + j0) * m, m, mr, nc, lane);
+                        {
+                            acc = nxt;
+                            if(tile + NW < nt * nt) nxt = chain_tile(tile + NW);
+                        }
                         else
                         {
                             if(staged)
