@@ -201,8 +201,9 @@ int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_o
 int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind, double* vals, double* rhs);
 
 /* in-kernel phase clocks of one instance since the last reset, 100 MHz ticks:
- * [0] device eval + MNA gather, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward wave fronts,
- * [4] forward+backward cooperative fronts, [5] backward wave fronts, [6..7] reserved */
+ * [0] device eval + MNA gather, [1] LU wave fronts (incl. the fused forward substitution), [2] LU cooperative fronts,
+ * [3] cooperative part of the backward pass, [4] Newton bookkeeping, [5] backward pass (all of it; a separate forward pass of
+ * the factor-reuse path is counted here too), [6] cooperative assembly, [7] cooperative block loops */
 int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8);
 /* the same plus, from slot 8 on, six values per cooperative-front layout (0 whole front in LDS, 1 pivot panels + pulled Schur
  * tiles, 2 chain link): assembly, block loop, Schur update, factor store [ticks], fronts [count], sum of m*m */

@@ -1150,8 +1150,10 @@ namespace pe
     PE_DEV void backward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
+        long long const cbw0 = tm.clock();
         for(int q = V.coop_ptr[part + 1] - 1; q >= V.coop_ptr[part]; --q) front_backward(tm, V, b, V.coop_list[q], lds, V.max_m, V.lds_coop_stage);
         tm.sync();
+        if(V.prof && tm.tid() == 0 && part == 0) V.prof[b * PE_PROF + 3] += tm.clock() - cbw0;  // cooperative part of the backward pass
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
             {
@@ -1184,12 +1186,10 @@ namespace pe
         if(!forward_done) permute_rhs(tm, V, b);
         long long const c0 = tm.clock();
         if(!forward_done) forward_part(tm, V, b, 0, lds);
-        long long const c1 = tm.clock();
         backward_part(tm, V, b, 0, lds);
         if(V.prof && t0 == 0)
         {
-            V.prof[b * PE_PROF + 3] += c1 - c0;
-            V.prof[b * PE_PROF + 5] += tm.clock() - c1;
+            V.prof[b * PE_PROF + 5] += tm.clock() - c0;  // backward (+ the separate forward pass of the factor-reuse path)
         }
         for(int k = t0; k < V.rows; k += T) x[V.col_src[k]] = w[k];
         tm.sync();

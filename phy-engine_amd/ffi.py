@@ -316,7 +316,7 @@ class Engine:
         fn = lib().pe_hip_get_phase_clocks
         fn.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
         self._chk(fn(self._h, instance, t.ctypes.data_as(C.POINTER(C.c_longlong))))
-        names = ["eval_stamp", "lu_wave", "lu_coop", "forward", "newton", "backward", "coop_asm", "coop_piv"]
+        names = ["eval_stamp", "lu_wave", "lu_coop", "backward_coop", "newton", "backward", "coop_asm", "coop_piv"]
         return {n: float(t[i]) / 100.0 for i, n in enumerate(names)}
 
     def checkpoint(self) -> bytes:
