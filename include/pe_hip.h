@@ -142,6 +142,9 @@ typedef struct pe_hip_run_stats
     double gpu_ms;          /* HIP-event time of the kernels of this call, on the engine's stream */
     int n_launches;
     int n_failed;           /* instances that stopped early */
+    double dominant_ms;     /* HIP-event time of the launches of the dominant kernel within gpu_ms: the resident kernel itself, or in the
+                               split schedule k_m2_factor_parts (k_m2_solve_parts when the factors are reused) */
+    int dominant_launches;
 } pe_hip_run_stats;
 
 int pe_hip_device_count(void);

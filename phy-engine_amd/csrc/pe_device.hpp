@@ -118,6 +118,7 @@ namespace pe
         int lds_sslot;          // doubles of one wavefront's solve scratch
         int lds_wave_stage{}, lds_coop_stage{};  // doubles of the staged block of a wavefront / of the workgroup in the triangular solves
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
+        int lds_solve_doubles;  // ... of the triangular-solve kernels of the split schedule
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;
         int max_newton;

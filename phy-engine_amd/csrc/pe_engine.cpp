@@ -77,6 +77,9 @@ struct pe_hip_engine
     int device{};
     hipStream_t stream{};
     hipEvent_t ev0{}, ev1{};
+    hipEvent_t evk0{}, evk1{};  // around the dominant launch of one split-schedule iteration
+    double dominant_ms{};       // accumulated over the current analyze call
+    int dominant_launches{};
     std::string err;
     pe_hip_options opt{};
     int lds_limit{65536};
@@ -140,11 +143,15 @@ namespace
     }
 
     // multi-workgroup schedule (one launch per phase and tree level) instead of the single resident kernel
+    // Large circuits always: the per-phase kernels fit their register budgets (the factor kernel spills 48 B / lane at 128 VGPRs,
+    // the resident kernel 580), which outweighs ~35 launches and one host round trip per Newton iteration once an iteration
+    // takes milliseconds.  Small circuits stay in the resident kernel (a time step is microseconds there).
     bool split_launch(pe_hip_engine const* h)
     {
-        if(h->V.n_parts > 1) return true;
-        char const* v = std::getenv("PHY_ENGINE_HIP_SPLIT");  // knob: the per-phase kernels also with one part per instance
-        return v && *v == '1';
+        char const* v = std::getenv("PHY_ENGINE_HIP_SPLIT");  // knob: 1 = always split, 0 = never (resident kernel, one part)
+        if(v && *v == '1') return true;
+        if(v && *v == '0') return false;
+        return h->V.n_parts > 1 || h->hc.rows >= 3000;
     }
 
     double r_open_of(pe_hip_engine const* h) { return h->opt.r_open > 0.0 ? h->opt.r_open : 1e12; }  // circuit.h:1012
@@ -202,7 +209,7 @@ namespace
         if(V.n_top_levels > 64) return fail(h, PE_HIP_ERR_INTERNAL, "assembly tree has more than 64 top levels");
         for(int l = 0; l < V.n_top_levels; ++l) V.top_cnt[l] = S.top_ptr[l + 1] - S.top_ptr[l];
         V.n_waves = so.n_waves;
-        V.high_occupancy = geometry_batch(batch) >= 384 ? 1 : 0;
+        V.high_occupancy = so.shared_cu;
         V.wave_m = so.wave_m;
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
@@ -217,6 +224,10 @@ namespace
             need = std::max(need, static_cast<long long>(so.n_waves) * V.lds_sslot);
             need = std::max(need, static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
             V.lds_doubles = static_cast<int>(need + 2);
+            // the triangular-solve kernels of the split schedule need far less: more of their workgroups fit a CU
+            long long const need_solve = std::max(static_cast<long long>(so.n_waves) * V.lds_sslot,
+                                                  static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
+            V.lds_solve_doubles = static_cast<int>(need_solve + 2);
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
@@ -226,19 +237,29 @@ namespace
     }
 
     // launch geometry -> symbolic limits: 8 wavefronts per workgroup, panels / wave slots carved from the LDS limit
+    int env_int0(char const* name, int def)
+    {
+        char const* v = std::getenv(name);
+        return v && *v ? std::atoi(v) : def;
+    }
+
     pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve = 384, int force_resident = 0)
     {
         int const batch = geometry_batch(batch_in);
         pe::SymbolicOptions so{};
-        // workgroup geometry by batch size (measured on MI355X, profiles/): few instances -> one big workgroup per CU;
-        // a sweep that oversubscribes the 256 CUs -> smaller workgroups, 2-4 resident per CU
-        if(batch >= 768)
+        // Workgroup geometry by batch size (measured on MI355X, profiles/ and scripts/sweep_split_*.sh).
+        // Large circuits run the split schedule (one launch per phase): from ~100 instances on, 256-thread workgroups at four per
+        // CU with every instance cut into 4 (8) parts -- >= 1024 workgroups for the low-register kernels; fewer instances keep one
+        // big workgroup per CU and more parts.  Small circuits run the resident kernel: geometry by the batch alone.
+        bool const large = rows >= 3000 && env_int0("PHY_ENGINE_HIP_SPLIT", -1) != 0;
+        bool const four_per_cu = large ? batch >= 96 : batch >= 768;
+        if(four_per_cu)
         {
             so.n_waves = 4;
             so.wave_m = 35;
-            so.wave_p = 32;
+            so.wave_p = 16;       // (small staged blocks: the backward kernel of the split schedule then fits 7-8 workgroups per CU)
             so.absorb_m = 35;
-            so.max_pivots = 48;
+            so.max_pivots = 32;
         }
         else if(batch >= 384)
         {
@@ -253,9 +274,11 @@ namespace
             so.wave_p = 20;
             so.max_pivots = 48;
         }
-        // one or few instances of a large circuit: spread each instance over several workgroups (multi-workgroup mode)
-        // (measured, profiles/: pays while instances x parts <= ~256 workgroups; 32-48 parts for a single M10k circuit)
-        if(rows >= 3000 && batch <= 128) so.n_parts = std::clamp(256 / std::max(1, batch), 1, 48);
+        if(large)
+        {
+            so.n_parts = batch >= 192 ? 4 : (batch >= 96 ? 8 : std::clamp(256 / std::max(1, batch), 1, 48));
+            so.part_cut = 1.0;
+        }
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
         auto env_int = [](char const* name, int def)
         {
@@ -270,11 +293,13 @@ namespace
         so.cut_factor = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_CUT_X10", static_cast<int>(so.cut_factor * 10.0)));
         so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
         so.n_parts = std::clamp(env_int("PHY_ENGINE_HIP_PARTS", so.n_parts), 1, 64);
+        if(env_int("PHY_ENGINE_HIP_SPLIT", -1) == 0) so.n_parts = 1;  // the resident kernel handles one part per instance
         so.part_cut = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_PART_CUT_X10", static_cast<int>(so.part_cut * 10.0)));
         so.wave_p = std::min(so.wave_p, so.max_pivots);
         // LDS share of one workgroup: the 128-VGPR kernels keep 16 wavefronts per CU resident (16 / n_waves workgroups)
-        int const resident =
-            force_resident > 0 ? force_resident : std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", batch >= 384 ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
+        bool const shared_cu = four_per_cu || batch >= 384;  // 128-VGPR kernels, 16 wavefronts per CU
+        int const resident = force_resident > 0 ? force_resident : std::clamp(env_int("PHY_ENGINE_HIP_RESIDENT", shared_cu ? std::max(1, 16 / so.n_waves) : 1), 1, 8);
+        so.shared_cu = (resident > 1) ? 1 : 0;
         long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
         // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
         while(static_cast<long long>(so.n_waves) * so.wave_m * (so.wave_m + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
@@ -473,10 +498,18 @@ namespace
         for(int it = 0; it < max_it && n_active > 0; ++it)
         {
             HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor));
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1));
             ++launches;
             HIPCHK(h, hipMemcpyAsync(S.flags.data(), h->V.flags, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
+            {
+                float kms = 0.f;
+                if(hipEventElapsedTime(&kms, h->evk0, h->evk1) == hipSuccess)
+                {
+                    h->dominant_ms += kms;
+                    ++h->dominant_launches;
+                }
+            }
             for(int b = 0; b < B; ++b)
             {
                 if(!S.active[b]) continue;
@@ -604,7 +637,7 @@ int pe_hip_create(int device, pe_hip_engine** out)
     auto h = std::make_unique<pe_hip_engine>();
     h->device = device;
     if(hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
-       hipEventCreate(&h->ev1) != hipSuccess)
+       hipEventCreate(&h->ev1) != hipSuccess || hipEventCreate(&h->evk0) != hipSuccess || hipEventCreate(&h->evk1) != hipSuccess)
     {
         g_create_error = "HIP runtime initialisation failed";
         return PE_HIP_ERR_NO_DEVICE;
@@ -629,6 +662,8 @@ void pe_hip_destroy(pe_hip_engine* h)
     h->csr.pool.release();
     (void)hipEventDestroy(h->ev0);
     (void)hipEventDestroy(h->ev1);
+    (void)hipEventDestroy(h->evk0);
+    (void)hipEventDestroy(h->evk1);
     (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -893,6 +928,8 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     if(!h || !h->loaded || nsteps < 0 || !(dt > 0.0)) return h ? fail(h, PE_HIP_ERR_ARG, "analyze_tr: bad arguments or no circuit") : PE_HIP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
     if(st) std::memset(st, 0, sizeof(*st));
+    h->dominant_ms = 0.0;
+    h->dominant_launches = 0;
     if(h->hc.rows == 0 || nsteps == 0) return PE_HIP_OK;
     int rc = ensure_symbolic(h, true, dt);
     if(rc != PE_HIP_OK) return rc;
@@ -933,6 +970,9 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     {
         st->gpu_ms = ms;
         st->n_launches = launches;
+        bool const split = h->dominant_launches > 0;
+        st->dominant_ms = split ? h->dominant_ms : ms;
+        st->dominant_launches = split ? h->dominant_launches : launches;
     }
     return rc;
 }
@@ -943,6 +983,8 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     if(mode != PE_HIP_MODE_OP && mode != PE_HIP_MODE_DC && mode != PE_HIP_MODE_TROP) return fail(h, PE_HIP_ERR_ARG, "analyze_dc: mode must be OP, DC or TROP");
     HIPCHK(h, hipSetDevice(h->device));
     if(st) std::memset(st, 0, sizeof(*st));
+    h->dominant_ms = 0.0;
+    h->dominant_launches = 0;
     if(h->hc.rows == 0) return PE_HIP_OK;
     int rc = ensure_symbolic(h, false, 0.0);
     if(rc != PE_HIP_OK) return rc;
@@ -968,6 +1010,9 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     {
         st->gpu_ms = ms;
         st->n_launches = 1;
+        bool const split = h->dominant_launches > 0;
+        st->dominant_ms = split ? h->dominant_ms : ms;
+        st->dominant_launches = split ? h->dominant_launches : 1;
     }
     return rc;
 }

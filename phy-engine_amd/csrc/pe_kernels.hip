@@ -336,7 +336,10 @@ namespace pe
         stamp(GridTeam{}, V, b);
     }
 
-    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_factor_parts(DevView V)
+    // (the four team kernels of the split schedule come in the two register budgets of the resident kernels: MINW = 2 for few
+    // big workgroups, MINW = 4 when several workgroups share a CU)
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_parts(DevView V)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -344,7 +347,8 @@ namespace pe
         if(!factor_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
-    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_factor_top(DevView V, int level)
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -363,7 +367,8 @@ namespace pe
         for(int k = tm.tid(); k < V.rows; k += tm.size()) w[k] = rhs[V.row_src[k]];
     }
 
-    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_solve_parts(DevView V, int backward)
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_parts(DevView V, int backward)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -373,7 +378,8 @@ namespace pe
             forward_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds);
     }
 
-    __global__ void __launch_bounds__(PE_THREADS, 2) k_m2_solve_top(DevView V, int level, int backward)
+    template <int MINW>
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_top(DevView V, int level, int backward)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -432,15 +438,19 @@ namespace pe
         return hipGetLastError();
     }
 
-    // one Newton iteration of every active instance in multi-workgroup mode: stamp -> LU -> solves -> Newton bits
-    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor)
+    // one Newton iteration of every active instance in the split schedule: stamp -> LU -> solves -> Newton bits.
+    // ev0 / ev1 (may be null): HIP events recorded around the dominant launch (k_m2_factor_parts, or the backward
+    // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
+    template <int MINW>
+    static hipError_t m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
+        size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
         {
-            hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts), lds);
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top), lds);
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts), lds);
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top), lds);
+            hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts<MINW>), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top<MINW>), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts<MINW>), lds_s);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_s);
             if(e != hipSuccess) return e;
         }
         int const B = V.batch, T = V.n_waves * 64;
@@ -451,19 +461,28 @@ namespace pe
         if(do_factor)
         {
             // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
-            hipLaunchKernelGGL(k_m2_factor_parts, dim3(V.n_parts, B), dim3(T), lds, st, V);
+            if(ev0) (void)hipEventRecord(ev0, st);
+            hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds, st, V);
+            if(ev1) (void)hipEventRecord(ev1, st);
             for(int l = 0; l < V.n_top_levels; ++l)
-                hipLaunchKernelGGL(k_m2_factor_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
+                hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
         }
         else
         {
-            hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 0);
-            for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 0);
+            hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds_s, st, V, 0);
+            for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 0);
         }
-        for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, 1);
-        hipLaunchKernelGGL(k_m2_solve_parts, dim3(V.n_parts, B), dim3(T), lds, st, V, 1);
+        for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 1);
+        if(!do_factor && ev0) (void)hipEventRecord(ev0, st);
+        hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds_s, st, V, 1);
+        if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
         hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);
         return hipGetLastError();
+    }
+
+    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1)
+    {
+        return V.high_occupancy ? m2_iteration<4>(st, V, mode, t, last_step, do_factor, ev0, ev1) : m2_iteration<2>(st, V, mode, t, last_step, do_factor, ev0, ev1);
     }
 
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt)

@@ -17,5 +17,6 @@ namespace pe
     hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor);
     // multi-workgroup mode (V.n_parts > 1)
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt);
-    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor);
+    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0 = nullptr,
+                                   hipEvent_t ev1 = nullptr);
 }  // namespace pe

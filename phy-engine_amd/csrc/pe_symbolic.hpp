@@ -30,7 +30,8 @@ namespace pe
         double cut_factor{1.0};   // a wave subtree may cost at most part_total / (cut_factor * n_waves)
         int n_parts{1};           // > 1: multi-workgroup mode, the tree below the level-1 cut is spread over this many workgroups
         double part_cut{1.5};     // a part subtree may cost at most total / (n_parts * part_cut)
-        long long panel_reserve{384};    // LDS doubles kept free behind the panels of a large front (right-hand-side column, staged child maps)
+        int shared_cu{};                 // the launch geometry keeps several workgroups per CU (128-VGPR kernel variants)
+    long long panel_reserve{384};    // LDS doubles kept free behind the panels of a large front (right-hand-side column, staged child maps)
     long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
 

@@ -58,7 +58,7 @@ class Info(C.Structure):
 
 class RunStats(C.Structure):
     _fields_ = [("steps", C.c_longlong), ("newton_iters", C.c_longlong), ("gpu_ms", C.c_double), ("n_launches", C.c_int),
-                ("n_failed", C.c_int)]
+                ("n_failed", C.c_int), ("dominant_ms", C.c_double), ("dominant_launches", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

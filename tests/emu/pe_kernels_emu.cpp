@@ -114,7 +114,7 @@ namespace pe
             if(V.active[b]) companion_update(SerialTeam{1}, V, b, dt);
         return hipSuccess;
     }
-    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor)
+    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t)
     {
         std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
         SerialTeam tm{V.n_waves};

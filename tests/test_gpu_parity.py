@@ -282,11 +282,15 @@ def test_dc_then_tr_switches_symbolic(eng, oracle_mod):
 
 # ---- multi-workgroup schedule (one circuit spread over several workgroups; knob PHY_ENGINE_HIP_PARTS) ----------
 @pytest.mark.parametrize("name,tol,parts", [("mesh32_nl", NL, 6), ("mesh32_lin", LIN, 16), ("ladder_c1", LIN, 4), ("mesh100_nl", NL, 1),
-                                            ("mesh100_nl", NL, 13), ("bridge_c2", NL, 2)])
+                                            ("mesh100_nl", NL, 13), ("bridge_c2", NL, 2), ("mesh100_nl", NL, -1), ("mesh32_nl", NL, -1)])
 def test_golden_parity_multi_workgroup(name, tol, parts, monkeypatch):
-    """Same goldens through the parts + top-levels schedule (pe_engine.cpp run_m2_tr) and, for M10k, through the
-    single-workgroup kernel (parts = 1) that batch = 1 no longer selects by itself."""
-    monkeypatch.setenv("PHY_ENGINE_HIP_PARTS", str(parts))
+    """Same goldens through the split schedule (parts + top levels, one launch per phase: pe_engine.cpp run_m2_tr) and, with
+    parts = -1, through the resident single-workgroup kernel (PHY_ENGINE_HIP_SPLIT=0 / =1 override the size rule:
+    circuits of >= 3000 rows run the split schedule, smaller ones the resident kernel)."""
+    if parts < 0:
+        monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", "0" if name.startswith("mesh100") else "1")
+    else:
+        monkeypatch.setenv("PHY_ENGINE_HIP_PARTS", str(parts))
     e = pe.ffi.Engine(device=0)
     try:
         meta, gx, deck = golden(name)
@@ -299,15 +303,15 @@ def test_golden_parity_multi_workgroup(name, tol, parts, monkeypatch):
 
 
 def test_multi_workgroup_batch_matches_single_workgroup(monkeypatch):
-    """A 4-instance M10k sweep: the multi-workgroup schedule (auto for batch <= 128) and the single-workgroup
-    kernel agree to rounding (different elimination trees => different summation order, so not bitwise)."""
+    """A 4-instance M10k sweep: the split multi-workgroup schedule (default for circuits of this size) and the resident
+    single-workgroup kernel agree to rounding (different elimination trees => different summation order, so not bitwise)."""
     deck = pe.deck.rc_mesh(100, 100, 1, True)
     out = []
     for parts in (1, 0):
         if parts:
-            monkeypatch.setenv("PHY_ENGINE_HIP_PARTS", str(parts))
+            monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", "0")
         else:
-            monkeypatch.delenv("PHY_ENGINE_HIP_PARTS", raising=False)
+            monkeypatch.delenv("PHY_ENGINE_HIP_SPLIT", raising=False)
         e = pe.ffi.Engine(device=0)
         e.set_options(g_min=0.0)
         e.load_deck(deck, batch=4)
@@ -318,6 +322,27 @@ def test_multi_workgroup_batch_matches_single_workgroup(monkeypatch):
         e.close()
     assert np.array_equal(out[0][1], out[1][1])
     assert np.max(np.abs(out[0][0] - out[1][0])) <= 1e-9 * np.max(np.abs(out[0][0]))
+
+
+@pytest.mark.parametrize("geometry", ["64", "128", "256", "1024"])
+@pytest.mark.parametrize("split", ["0", "auto"])
+def test_launch_geometries_on_large_circuit(geometry, split, monkeypatch):
+    """M10k golden under every launch geometry the batch-size policy selects (symbolic_options in pe_engine.cpp: 8 wavefronts x
+    1 workgroup per CU, 4 x 4 with 4 or 8 parts), each in the split schedule and in the resident kernel; 2 identical instances."""
+    monkeypatch.setenv("PHY_ENGINE_HIP_GEOMETRY_BATCH", geometry)
+    if split != "auto":
+        monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", split)
+    e = pe.ffi.Engine(device=0)
+    try:
+        meta, gx, deck = golden("mesh100_nl")
+        snaps, trace, fail = run_engine_case(e, meta, deck, batch=2)
+        assert fail == -1 and len(snaps) == len(gx)
+        for b in range(2):
+            assert max_err(snaps[:, b, :], gx, *NL) <= 1.0
+        assert list(trace) == meta["newton_iters"]
+        assert (e.info()["n_parts"] > 1) == (split == "auto")
+    finally:
+        e.close()
 
 
 def test_reuse_factor_multi_workgroup():
