@@ -228,10 +228,27 @@ def main():
 
     if rank == 0:
         bpi = bytes_per_iteration(info)
-        # dominant kernel = k_tr_steps (the whole resident step).  Its launches of the timed region processed
-        # (local) newton_iters iterations + steps companion updates; duration from HIP events on the engine's stream.
+        # Whole hot path: the launches of the timed region processed (local) newton_iters iterations + steps companion updates;
+        # duration from HIP events on the engine's stream.
         local_bytes = bpi["iter"] * st["newton_iters"] + bpi["companion_per_step"] * st["steps"]
-        achieved = local_bytes / (st["gpu_ms"] * 1e-3) / 1e9
+        path_achieved = local_bytes / (st["gpu_ms"] * 1e-3) / 1e9
+        split = info.get("n_parts", 1) > 1 or st["dominant_launches"] != st["n_launches"]
+        if split:
+            # Split schedule (one launch per phase): the dominant kernel is k_m2_factor_parts -- assembly + LU of every front below
+            # the top levels with the right-hand side carried along (fused forward substitution).  Its algorithmic bytes per
+            # Newton iteration: the factor bytes and the forward half of the solve bytes, scaled by the share of the factor
+            # entries those fronts hold.  Duration: HIP events recorded around that launch alone (pe_kernels.hip m2_iteration).
+            share = 1.0 - info["nnz_lu_stored_top"] / max(1, info["nnz_lu_stored"])
+            dom_bytes_iter = share * (bpi["factor"] + 0.5 * bpi["solve"])
+            kernel = "k_m2_factor_parts<%d>" % (4 if info["n_wavefronts"] <= 4 else 2)
+        else:
+            share = 1.0
+            dom_bytes_iter = bpi["iter"]
+            kernel = "k_tr_steps"
+        dom_ms = st["dominant_ms"]
+        dom_launches = max(1, st["dominant_launches"])
+        dom_bytes = dom_bytes_iter * st["newton_iters"] + (0 if split else bpi["companion_per_step"] * st["steps"])
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "transient steps/sec (+ Newton iters/sec), 10k-node RC mesh",
             "value": steps_total / el,
@@ -252,10 +269,13 @@ def main():
                        "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_per_gpu": B,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "kernel": "k_tr_steps" if info.get("n_parts", 1) <= 1 else "multi-workgroup schedule: k_m2_* (one launch per phase and tree level)",
-                         "bytes_per_newton_iter": bpi["iter"], "launches": st["n_launches"],
-                         "avg_launch_ms": st["gpu_ms"] / max(1, st["n_launches"])},
+                         "traffic": None, "kernel": kernel,
+                         "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches, "bytes_per_launch": dom_bytes / dom_launches,
+                         "bytes_per_newton_iter": dom_bytes_iter, "share_of_factor_entries": share,
+                         "time_share_of_hot_path": dom_ms / st["gpu_ms"],
+                         "whole_path": {"achieved": path_achieved, "frac": path_achieved / HBM_PEAK_GBS, "bytes_per_newton_iter": bpi["iter"],
+                                        "gpu_ms": st["gpu_ms"], "schedule": "split: k_m2_eval/stamp/winit/factor_parts/factor_top x levels/"
+                                        "solve_top x levels/solve_parts/finish per Newton iteration" if split else "resident k_tr_steps"}},
             "reduce_ms": reduce_ms,
             "stats_checksum": float(np.sum(stats[0])),
             "engine": {k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
@@ -266,7 +286,9 @@ def main():
                 tj = json.load(open(tp))
                 if tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W:
                     # measured offline with rocprofv3 --pmc on this same command (profiles/README.md); bytes per launch
-                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"] * (st["n_launches"] and 1)
+                    if tj.get("kernel", "k_tr_steps").split("<")[0] != kernel.split("<")[0]:
+                        raise KeyError("traffic measured for another kernel")
+                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
                     line["roofline"]["traffic_note"] = tj.get("note", "")
             except Exception:
                 pass

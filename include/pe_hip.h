@@ -133,6 +133,7 @@ typedef struct pe_hip_info
     int n_top_levels; /* launches of the top of the tree in that schedule */
     int n_wavefronts; /* wavefronts per workgroup of the launch geometry chosen for this batch */
     int lds_bytes;    /* dynamic LDS per workgroup */
+    long long nnz_lu_stored_top; /* part of nnz_lu_stored held by the fronts of the top levels (split schedule: k_m2_factor_top / k_m2_solve_top) */
 } pe_hip_info;
 
 typedef struct pe_hip_run_stats

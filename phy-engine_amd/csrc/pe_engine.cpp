@@ -880,6 +880,8 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
         out->n_top_levels = h->V.n_top_levels;
         out->n_wavefronts = h->V.n_waves;
         out->lds_bytes = h->V.lds_doubles * 8;
+        for(int s = 0; s < h->sym.nfronts; ++s)
+            if(h->sym.f_kind[s] == 2) out->nnz_lu_stored_top += 2LL * h->sym.f_p[s] * h->sym.f_u[s] + static_cast<long long>(h->sym.f_p[s]) * h->sym.f_p[s];
         out->n_row_swaps = h->sym.n_row_swaps;
         out->factor_flops = h->sym.flops;
     }

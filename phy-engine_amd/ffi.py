@@ -50,7 +50,7 @@ class Info(C.Structure):
                 ("tree_depth", C.c_int), ("n_row_swaps", C.c_int), ("factor_flops", C.c_double),
                 ("bytes_per_instance", C.c_longlong), ("n_r", C.c_int), ("n_c", C.c_int), ("n_l", C.c_int), ("n_v", C.c_int),
                 ("n_i", C.c_int), ("n_d", C.c_int), ("nonlinear", C.c_int), ("n_parts", C.c_int), ("n_top_levels", C.c_int),
-                ("n_wavefronts", C.c_int), ("lds_bytes", C.c_int)]
+                ("n_wavefronts", C.c_int), ("lds_bytes", C.c_int), ("nnz_lu_stored_top", C.c_longlong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Developer tool: profiles/r01_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/profile_round.sh.
+
+  python scripts/pmc_traffic.py gpurun_out/<tag>_fetch gpurun_out/<tag>_write gpurun_out/<tag>_bench.json [kernel substring]
+
+Sums FETCH_SIZE / WRITE_SIZE (KiB) over the dispatches of the dominant kernel and divides by their count: HBM bytes per
+launch, the same normalisation as roofline.achieved in bench.py.  Raw KiB x 1024, not doubled (see "note")."""
+import csv, glob, json, os, sys
+
+fetch_dir, write_dir, bench_json = sys.argv[1:4]
+line = json.loads(open(bench_json).read().strip().splitlines()[-1])
+kernel = sys.argv[4] if len(sys.argv) > 4 else line["roofline"]["kernel"].split("<")[0]
+
+
+def total(d, counter):
+    s, n = 0.0, 0
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                s += float(row["Counter_Value"])
+                n += 1
+    return s, n
+
+
+f, nf = total(fetch_dir, "FETCH_SIZE")
+w, nw = total(write_dir, "WRITE_SIZE")
+assert nf and nf == nw, (nf, nw)
+out = {
+    "instances_per_gpu": line["config"]["instances_per_gpu"], "nonlinear": "-NL" in line["config"]["workload"], "mesh": 100,
+    "kernel": kernel, "dispatches": nf, "FETCH_SIZE_KiB_per_launch": f / nf, "WRITE_SIZE_KiB_per_launch": w / nw,
+    "hbm_bytes_per_launch": (f / nf + w / nw) * 1024.0,
+    "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"],
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --no-cpu-baseline --no-single`, "
+            "averaged over every dispatch of the kernel (warm-up included: same work per launch up to the converged instances); raw KiB x 1024, "
+            "NOT doubled: the guide's x2 FETCH_SIZE correction is calibrated for 16-B/lane streams, this kernel's 8-B/lane gather pattern is uncalibrated",
+}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
