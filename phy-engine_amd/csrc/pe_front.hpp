@@ -489,7 +489,7 @@ namespace pe
     // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
     // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
     template <class Team>
-    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, bool profile, bool fuse)
+    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, int profile, bool fuse)
     {
         int const s = tm.uniform(s_in);
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
@@ -531,6 +531,7 @@ namespace pe
             else
                 Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
         }
+        long long const cka = tm.clock();
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
         if(ch1 > ch0) tm.sync();
         else
@@ -654,75 +655,86 @@ namespace pe
         for(int k0 = 0; k0 < p; k0 += NB)
         {
             int const kb = p - k0 < NB ? p - k0 : NB;
-            // (a0) diagonal block, wavefront 0: LU of the kb x kb block in registers (tm.diag_lu8), L stored scaled
-            int bad = 0;
-            tm.for_each_wave(
-                [&](int w, int lane, int NL)
-                {
-                    if(w == 0) bad = tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
-                });
-            if(tm.sync_or(bad)) return false;
-            // (a1) rows below the block (L) and columns right of it (U): one thread each; the 8 x 8 block and the
-            // thread's own row / column sit in registers, so the dependent chain is pure ALU
+            if(tm.single_wave())
             {
-                int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
-                int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
-                int const ncols = ncolL + u;              // plus every column of the U panel
-                int const ngc = fuse ? 1 : 0;             // plus the right-hand-side column
-                for(int q = t0; q < nrows + ncols + ngc; q += T)
+                // one wavefront owns the front (m <= 64): diagonal block, rows below it and columns right of it in ONE pass over
+                // registers, cross-lane traffic on v_readlane (tm.block_step)
+                int bad = 0;
+                tm.for_each_wave([&](int, int lane, int) { bad = tm.block_step(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, lane); });
+                if(tm.sync_or(bad)) return false;
+            }
+            else
+            {
+                // (a0) diagonal block, wavefront 0: LU of the kb x kb block in registers (tm.diag_lu8), L stored scaled
+                int bad = 0;
+                tm.for_each_wave(
+                    [&](int w, int lane, int NL)
+                    {
+                        if(w == 0) bad = tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
+                    });
+                if(tm.sync_or(bad)) return false;
+                // (a1) rows below the block (L) and columns right of it (U): one thread each; the 8 x 8 block and the
+                // thread's own row / column sit in registers, so the dependent chain is pure ALU
                 {
-                    double x[NB];
-                    if(q < nrows)
+                    int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
+                    int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
+                    int const ncols = ncolL + u;              // plus every column of the U panel
+                    int const ngc = fuse ? 1 : 0;             // plus the right-hand-side column
+                    for(int q = t0; q < nrows + ncols + ngc; q += T)
                     {
-                        // x * U11 = a  (row of L): needs the upper triangle of the block
-                        double* row = Lp + (k0 + kb + q) + k0 * m;
-#pragma unroll
-                        for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
-#pragma unroll
-                        for(int kk = 0; kk < NB; ++kk)
+                        double x[NB];
+                        if(q < nrows)
                         {
-                            if(kk < kb)
+                            // x * U11 = a  (row of L): needs the upper triangle of the block
+                            double* row = Lp + (k0 + kb + q) + k0 * m;
+    #pragma unroll
+                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
+    #pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
                             {
-                                double ucol[NB];
-#pragma unroll
-                                for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? Lp[(k0 + r) + (k0 + kk) * m] : 0.0;
-                                double const rdiag = 1.0 / ucol[kk];  // independent of the chain below: overlaps with it
-                                double acc = x[kk];
-#pragma unroll
-                                for(int r = 0; r < NB; ++r)
-                                    if(r < kk) acc -= x[r] * ucol[r];
-                                x[kk] = acc * rdiag;
+                                if(kk < kb)
+                                {
+                                    double ucol[NB];
+    #pragma unroll
+                                    for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? Lp[(k0 + r) + (k0 + kk) * m] : 0.0;
+                                    double const rdiag = tm.rcp(ucol[kk]);  // independent of the chain below: overlaps with it
+                                    double acc = x[kk];
+    #pragma unroll
+                                    for(int r = 0; r < NB; ++r)
+                                        if(r < kk) acc -= x[r] * ucol[r];
+                                    x[kk] = acc * rdiag;
+                                }
                             }
+    #pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                                if(kk < kb) row[kk * m] = x[kk];
                         }
-#pragma unroll
-                        for(int kk = 0; kk < NB; ++kk)
-                            if(kk < kb) row[kk * m] = x[kk];
-                    }
-                    else
-                    {
-                        // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
-                        int const jc = q - nrows;
-                        double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : (jc < ncols ? Up + (jc - ncolL) * ldu + k0 : g + k0);
-#pragma unroll
-                        for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
-#pragma unroll
-                        for(int kk = 1; kk < NB; ++kk)
+                        else
                         {
-                            if(kk < kb)
+                            // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
+                            int const jc = q - nrows;
+                            double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : (jc < ncols ? Up + (jc - ncolL) * ldu + k0 : g + k0);
+    #pragma unroll
+                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
+    #pragma unroll
+                            for(int kk = 1; kk < NB; ++kk)
                             {
-                                double lrow[NB];
-#pragma unroll
-                                for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? Lp[(k0 + kk) + (k0 + r) * m] : 0.0;
-                                double acc = x[kk];
-#pragma unroll
-                                for(int r = 0; r < NB; ++r)
-                                    if(r < kk) acc -= lrow[r] * x[r];
-                                x[kk] = acc;
+                                if(kk < kb)
+                                {
+                                    double lrow[NB];
+    #pragma unroll
+                                    for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? Lp[(k0 + kk) + (k0 + r) * m] : 0.0;
+                                    double acc = x[kk];
+    #pragma unroll
+                                    for(int r = 0; r < NB; ++r)
+                                        if(r < kk) acc -= lrow[r] * x[r];
+                                    x[kk] = acc;
+                                }
                             }
+    #pragma unroll
+                            for(int kk = 0; kk < NB; ++kk)
+                                if(kk < kb) col[kk] = x[kk];
                         }
-#pragma unroll
-                        for(int kk = 0; kk < NB; ++kk)
-                            if(kk < kb) col[kk] = x[kk];
                     }
                 }
             }
@@ -784,7 +796,7 @@ namespace pe
             tm.sync();
         }
         long long const ck2 = tm.clock();
-        if(profile && V.prof && t0 == 0)
+        if(profile == 1 && V.prof && t0 == 0)
         {
             V.prof[b * PE_PROF + 6] += ck1 - ck0;
             V.prof[b * PE_PROF + 7] += ck2 - ck1;
@@ -930,13 +942,14 @@ namespace pe
         tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
         if(profile && V.prof && t0 == 0)
         {
-            long long* q = V.prof + b * PE_PROF + 8 + 6 * (full ? 0 : (chain ? 2 : 1));
+            long long* q = V.prof + b * PE_PROF + (profile == 2 ? 32 : 8 + 6 * (full ? 0 : (chain ? 2 : 1)));
             q[0] += ck1 - ck0;
             q[1] += ck2 - ck1;
             q[2] += ck3 - ck2;
             q[3] += tm.clock() - ck3;
             q[4] += 1;
             q[5] += m * m;
+            if(profile == 2) q[6] += cka - ck0;  // of the assembly: zeroing + this front's own entries of A
         }
         return true;
     }
@@ -955,7 +968,7 @@ namespace pe
                 double* slot = lds + static_cast<long long>(w) * V.lds_slot;
                 int const q1 = tm.uniform(wp[w + 1]);
                 for(int q = tm.uniform(wp[w]); q < q1; ++q)
-                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, false, fuse))
+                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, (w == 0 && part == 0) ? 2 : 0, fuse))
                     {
                         fail = 1;
                         break;
@@ -966,7 +979,7 @@ namespace pe
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
         for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q)
-            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, true, fuse)) return false;
+            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, 1, fuse)) return false;
         if(V.prof && tm.tid() == 0 && part == 0)
         {
             V.prof[b * PE_PROF + 1] += c1 - c0;

@@ -42,6 +42,16 @@ namespace pe
         // derived from the wavefront's index): moved to an SGPR so that the loads it indexes become scalar loads and
         // the address arithmetic leaves the vector ALU
         __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+        // 1 / d for a pivot: v_rcp_f64 + two Newton steps (no v_div_scale / v_div_fmas / v_div_fixup sequence: pivots are
+        // checked finite and non-zero before, and circuit values sit far from the subnormal range)
+        __device__ __forceinline__ double rcp(double d) const
+        {
+            double r = __builtin_amdgcn_rcp(d);
+            double e = __builtin_fma(-d, r, 1.0);
+            r = __builtin_fma(e, r, r);
+            e = __builtin_fma(-d, r, 1.0);
+            return __builtin_fma(e, r, r);
+        }
         __device__ __forceinline__ long long clock() const { return static_cast<long long>(wall_clock64()); }
 
         // LU (no pivoting) of a kb x kb block (kb <= 8) held one entry per lane: lane l <-> (row l&7, col l>>3).
@@ -60,7 +70,7 @@ namespace pe
                 double const lrk = __shfl(v, r + 8 * kk);
                 double const ukc = __shfl(v, kk + 8 * c);
                 if(kk < kb && (piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))) bad = 1;
-                double const l = lrk * (1.0 / piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
+                double const l = lrk * rcp(piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
                 if(r > kk && c > kk) v -= l * ukc;
                 if(r > kk && c == kk) v = l;
             }
@@ -74,6 +84,70 @@ namespace pe
             int const lo = __builtin_amdgcn_readlane(__double2loint(v), k);
             int const hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
             return __hiloint2double(hi, lo);
+        }
+        // One block step (kb <= 8 pivots from k0) of a front that ONE wavefront owns (m <= 64).
+        // Rows: lane i holds row k0 + i of the block's columns in registers and the pivot row of step kk comes from lane kk by
+        // v_readlane -- the LU of the diagonal block and the solve of the rows below it (x U11 = a) are the same elimination,
+        // with no LDS round trip on the dependent chain.  Columns: lane j holds the block rows of one column right of the
+        // block (rest of the L panel, the U panel, the right-hand-side column) and solves L11 y = a with the multipliers read
+        // from the row lanes' registers.  Same operation order as diag_lu8 + the per-thread solves of front_factor.
+        __device__ __forceinline__ int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse,
+                                                  int lane) const
+        {
+            bool const own = lane < m - k0;
+            double* row = Lp + (k0 + lane) + k0 * m;
+            double v[8];
+#pragma unroll
+            for(int c = 0; c < 8; ++c) v[c] = (own && c < kb) ? row[c * m] : 0.0;
+            int bad = 0;
+#pragma unroll
+            for(int kk = 0; kk < 8; ++kk)
+            {
+                if(kk < kb)
+                {
+                    double const piv = bcast(v[kk], kk);
+                    if(piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308)) bad = 1;
+                    double const l = v[kk] * rcp(piv);
+                    bool const below = lane > kk;
+#pragma unroll
+                    for(int c = kk + 1; c < 8; ++c)
+                        if(c < kb)
+                        {
+                            double const uc = bcast(v[c], kk);
+                            if(below) v[c] -= l * uc;
+                        }
+                    if(below) v[kk] = l;
+                }
+            }
+            if(own)
+            {
+#pragma unroll
+                for(int c = 0; c < 8; ++c)
+                    if(c < kb) row[c * m] = v[c];
+            }
+            int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
+            bool const ownc = lane < ncols;
+            double* col = lane < ncolL ? Lp + (k0 + kb + lane) * m + k0 : (lane < ncolL + u ? Up + (lane - ncolL) * ldu + k0 : g + k0);
+            double x[8];
+#pragma unroll
+            for(int kk = 0; kk < 8; ++kk) x[kk] = (ownc && kk < kb) ? col[kk] : 0.0;
+#pragma unroll
+            for(int kk = 1; kk < 8; ++kk)
+                if(kk < kb)
+                {
+                    double acc = x[kk];
+#pragma unroll
+                    for(int r = 0; r < 8; ++r)
+                        if(r < kk) acc -= bcast(v[r], kk) * x[r];
+                    x[kk] = acc;
+                }
+            if(ownc)
+            {
+#pragma unroll
+                for(int kk = 0; kk < 8; ++kk)
+                    if(kk < kb) col[kk] = x[kk];
+            }
+            return bad;
         }
         // Triangular solves of the triangular-solve phase, p <= 64, one wavefront: lane i owns t[i]; the dependent chain
         // runs on lane broadcasts, the matrix columns (LDS, independent of the chain) are fetched four steps ahead.
@@ -214,6 +288,7 @@ namespace pe
         __device__ __forceinline__ void sync_lds() const { wave_fence_lds(); }
         __device__ __forceinline__ int sync_or(int v) const { return __any(v); }
         __device__ __forceinline__ int n_waves() const { return 1; }
+        __device__ __forceinline__ bool single_wave() const { return true; }
         template <class F>
         __device__ __forceinline__ void for_each_wave(F&& body) const
         {
@@ -238,6 +313,7 @@ namespace pe
         }
         __device__ __forceinline__ int sync_or(int v) const { return __syncthreads_or(v); }
         __device__ __forceinline__ int n_waves() const { return static_cast<int>(blockDim.x) >> 6; }
+        __device__ __forceinline__ bool single_wave() const { return false; }
         template <class F>
         __device__ __forceinline__ void for_each_wave(F&& body) const
         {
@@ -354,7 +430,7 @@ namespace pe
         if(!V.active[b]) return;
         HipTeam tm;
         int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, false, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)

@@ -14,6 +14,7 @@ namespace pe
         SerialTeam wave_team(int) const { return SerialTeam{1}; }
         int tid() const { return 0; }
         int uniform(int v) const { return v; }
+        double rcp(double d) const { return 1.0 / d; }
         void sync_lds() const {}
         int size() const { return 1; }
         void sync() const {}
@@ -27,6 +28,30 @@ namespace pe
             for(int w = 0; w < nw; ++w) body(w, 0, 1);
         }
         int n_waves() const { return nw; }
+        bool single_wave() const { return nw == 1; }
+        int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int) const
+        {
+            for(int kk = 0; kk < kb; ++kk)
+            {
+                double const piv = Lp[(k0 + kk) + (k0 + kk) * m];
+                if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
+                double const r = 1.0 / piv;
+                for(int i = k0 + kk + 1; i < m; ++i)
+                {
+                    double const l = Lp[i + (k0 + kk) * m] * r;
+                    for(int c = kk + 1; c < kb; ++c) Lp[i + (k0 + c) * m] -= l * Lp[(k0 + kk) + (k0 + c) * m];
+                    Lp[i + (k0 + kk) * m] = l;
+                }
+            }
+            int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
+            for(int j = 0; j < ncols; ++j)
+            {
+                double* col = j < ncolL ? Lp + (k0 + kb + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                for(int kk = 1; kk < kb; ++kk)
+                    for(int r = 0; r < kk; ++r) col[kk] -= Lp[(k0 + kk) + (k0 + r) * m] * col[r];
+            }
+            return 0;
+        }
         int diag_lu8(double* blk, int ld, int kb, int) const
         {
             for(int kk = 0; kk < kb; ++kk)
@@ -136,7 +161,7 @@ namespace pe
                     if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
                 for(int l = 0; l < V.n_top_levels; ++l)
                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, false, true)) V.flags[b] |= 4;
+                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, 0, true)) V.flags[b] |= 4;
             }
             else
             {
