@@ -15,10 +15,10 @@ namespace pe
     // in-kernel phase clocks per instance: [0] eval+stamp, [1] LU wave fronts, [2] LU cooperative fronts, [3] forward, [4] -,
     // [5] backward, [6] cooperative assembly, [7] cooperative block loop; then per cooperative front layout L = 0 whole-front,
     // 1 panel+pull, 2 chain link at 8 + 6 L: assembly, block loop, Schur, store, fronts, sum of m*m; [26..31] wave-phase time of
-    // wavefronts 0..5 of part 0; [32..37] the same six figures for the wave fronts of wavefront 0 of part 0
+    // wavefronts 0..5 of part 0; [32..38] the same six figures (+ own-entries share of the assembly) for the wave fronts of wavefront 0 of part 0; [40..47] factorisation time of parts 0..7
     enum : int
     {
-        PE_PROF = 40
+        PE_PROF = 48
     };
 
     // diode parameter columns after host-side prepare_foundation (PN_junction.h:296-354)

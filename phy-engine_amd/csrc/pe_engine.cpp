@@ -379,6 +379,26 @@ namespace
         h->sym_pool.release();
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
+        {
+            // The matrix values live in FRONT-ASSEMBLY order on the device: slot e of `aval` is the e-th assembled entry
+            // (asm_slot is a permutation of the CSR slots), so a front reads its own entries of A as one contiguous run with no
+            // index indirection.  The contribution lists of the stamp are permuted to match.
+            auto const& S = h->sym;
+            auto const& hc = h->hc;
+            size_t const nnz = hc.ci.size();
+            std::vector<int> ptr2(nnz + 1, 0), src2;
+            src2.reserve(hc.a_src.size());
+            for(size_t e = 0; e < nnz; ++e)
+            {
+                int const slot = S.asm_slot[e];
+                src2.insert(src2.end(), hc.a_src.begin() + hc.a_ptr[slot], hc.a_src.begin() + hc.a_ptr[slot + 1]);
+                ptr2[e + 1] = static_cast<int>(src2.size());
+            }
+            if(src2.empty()) src2.push_back(0);
+            HIPCHK(h, h->sym_pool.upload(h->V.a_ptr, ptr2));
+            HIPCHK(h, h->sym_pool.upload(h->V.a_src, src2));
+            h->V.asm_slot = nullptr;  // identity (pe_front.hpp front_factor); the solve_csr_real seam keeps CSR order + the map
+        }
         h->sym_class = cls;
         h->fact_valid = false;
         h->analyze_ms = ms_since(t0);
@@ -1067,7 +1087,13 @@ int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind
     if(row_ptr) std::copy(hc.rp.begin(), hc.rp.end(), row_ptr);
     if(col_ind) std::copy(hc.ci.begin(), hc.ci.end(), col_ind);
     HIPCHK(h, hipSetDevice(h->device));
-    if(vals) HIPCHK(h, hipMemcpy(vals, h->V.aval + static_cast<size_t>(instance) * hc.ci.size(), hc.ci.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if(vals)
+    {
+        if(h->sym_class < 0) return fail(h, PE_HIP_ERR_ARG, "get_matrix: no analysis has run yet");
+        std::vector<double> tmp(hc.ci.size());  // device order = front-assembly order (ensure_symbolic)
+        HIPCHK(h, hipMemcpy(tmp.data(), h->V.aval + static_cast<size_t>(instance) * hc.ci.size(), hc.ci.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for(size_t e = 0; e < tmp.size(); ++e) vals[h->sym.asm_slot[e]] = tmp[e];
+    }
     if(rhs) HIPCHK(h, hipMemcpy(rhs, h->V.rhs + static_cast<size_t>(instance) * hc.rows, hc.rows * sizeof(double), hipMemcpyDeviceToHost));
     return PE_HIP_OK;
 }

@@ -516,21 +516,28 @@ namespace pe
         int const c0 = V.f_col0[s];
         double* w = V.w + static_cast<long long>(b) * V.rows;
         long long const ck0 = tm.clock();
+        // the entries of A owned by this front and its slice of the right-hand side: their loads depend on nothing a previous
+        // front wrote -- requested first, they fly behind the zeroing of the front (and that front's stores still in flight)
+        int const e0 = V.f_asm_ptr[s] + t0, e1 = V.f_asm_ptr[s + 1];
+        int const pos0 = e0 < e1 ? V.asm_pos[e0] : 0;
+        double const v0 = e0 < e1 ? a[V.asm_slot ? V.asm_slot[e0] : e0] : 0.0;
+        double const w0 = (fuse && t0 < p) ? w[c0 + t0] : 0.0;
         for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
         if(fuse)
-            for(int i = t0; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
-        tm.sync_lds();
-        // the entries of A owned by this front first: their loads do not depend on anything a previous front wrote, so
-        // they overlap with that front's stores still in flight
-        for(int e = V.f_asm_ptr[s] + t0; e < V.f_asm_ptr[s + 1]; e += T)
         {
-            int const pos = V.asm_pos[e];
+            if(t0 < m) g[t0] = w0;
+            for(int i = t0 + T; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
+        }
+        tm.sync_lds();
+        auto place = [&](int pos, double v)
+        {
             int const r = pos >> 16, c = pos & 0xffff;
-            double const v = a[V.asm_slot[e]];
             if(c < p) Lp[r + c * m] += v;
             else
                 Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
-        }
+        };
+        if(e0 < e1) place(pos0, v0);
+        for(int e = e0 + T; e < e1; e += T) place(V.asm_pos[e], a[V.asm_slot ? V.asm_slot[e] : e]);
         long long const cka = tm.clock();
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
         if(ch1 > ch0) tm.sync();
@@ -985,6 +992,7 @@ namespace pe
             V.prof[b * PE_PROF + 1] += c1 - c0;
             V.prof[b * PE_PROF + 2] += tm.clock() - c1;
         }
+        if(V.prof && tm.tid() == 0 && part < 8) V.prof[b * PE_PROF + 40 + part] += tm.clock() - c0;
         return true;
     }
 

@@ -417,10 +417,12 @@ namespace pe
     template <int MINW>
     __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_parts(DevView V)
     {
-        int const b = static_cast<int>(blockIdx.y);
+        // x = instance, y = part: workgroups are dispatched part by part (parts in descending cost, pe_symbolic.cpp), so the
+        // last ones to start are the cheapest
+        int const b = static_cast<int>(blockIdx.x);
         if(!V.active[b]) return;
         HipTeam tm;
-        if(!factor_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        if(!factor_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
     }
 
     template <int MINW>
@@ -446,12 +448,12 @@ namespace pe
     template <int MINW>
     __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_parts(DevView V, int backward)
     {
-        int const b = static_cast<int>(blockIdx.y);
+        int const b = static_cast<int>(blockIdx.x);  // x = instance, y = part (see k_m2_factor_parts)
         if(!V.active[b]) return;
         HipTeam tm;
-        if(backward) backward_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds);
+        if(backward) backward_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds);
         else
-            forward_part(tm, V, b, static_cast<int>(blockIdx.x), pe_lds);
+            forward_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds);
     }
 
     template <int MINW>
@@ -538,19 +540,19 @@ namespace pe
         {
             // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
             if(ev0) (void)hipEventRecord(ev0, st);
-            hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds, st, V);
+            hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
             for(int l = 0; l < V.n_top_levels; ++l)
                 hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
         }
         else
         {
-            hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds_s, st, V, 0);
+            hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 0);
             for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 0);
         }
         for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 1);
         if(!do_factor && ev0) (void)hipEventRecord(ev0, st);
-        hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(V.n_parts, B), dim3(T), lds_s, st, V, 1);
+        hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 1);
         if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
         hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);
         return hipGetLastError();

@@ -811,6 +811,19 @@ namespace pe
                 part_total[pidx] += sub[r];
                 mark_subtree(r, [&](int t) { part_of[t] = pidx; });
             }
+            // parts in descending cost: the launch dispatches workgroups part by part, the cheapest last (shortest tail)
+            ivec order(K), rank(K);
+            for(int q = 0; q < K; ++q) order[q] = q;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return part_total[a] > part_total[b]; });
+            std::vector<double> sorted_total(K);
+            for(int q = 0; q < K; ++q)
+            {
+                rank[order[q]] = q;
+                sorted_total[q] = part_total[order[q]];
+            }
+            part_total = sorted_total;
+            for(int t = 0; t < nf; ++t)
+                if(part_of[t] >= 0) part_of[t] = rank[part_of[t]];
         }
         else
             part_total[0] = total;

@@ -351,16 +351,17 @@ class Engine:
 
     def phase_clocks_coop(self, instance=0):
         """Per-layout breakdown of the cooperative fronts (see pe_hip_get_phase_clocks_ex), microseconds / counts."""
-        t = np.zeros(40, dtype=np.int64)
+        t = np.zeros(48, dtype=np.int64)
         n = C.c_int()
         fn = lib().pe_hip_get_phase_clocks_ex
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
-        self._chk(fn(self._h, instance, 40, t.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(n)))
+        self._chk(fn(self._h, instance, 48, t.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(n)))
         out = {}
         for L, name in enumerate(("whole", "panel", "chain", "wave0")):
             q = t[8 + 6 * L: 14 + 6 * L] if L < 3 else t[32:38]
             out[name] = {"asm": q[0] / 100.0, "piv": q[1] / 100.0, "schur": q[2] / 100.0, "store": q[3] / 100.0, "fronts": int(q[4]), "sum_m2": int(q[5])}
         out["wave0"]["asm_own"] = t[38] / 100.0
+        out["part_us"] = [float(v) / 100.0 for v in t[40:48]]
         out["wave_phase_us"] = [float(v) / 100.0 for v in t[26:32]]
         return out
 

@@ -25,6 +25,7 @@ for nonlinear in (False, True):
         if os.environ.get("COOP") == "1":
             pc = eng.phase_clocks_coop(0)
             print("    wave phase per wavefront us/iter: " + " ".join(f"{v/it:.0f}" for v in pc.pop("wave_phase_us")), flush=True)
+            print("    factorisation time per part us/iter: " + " ".join(f"{v/it:.0f}" for v in pc.pop("part_us")), flush=True)
             for name, q in pc.items():
                 print(f"    coop {name}: fronts/iter={q['fronts']/it:.1f} sum_m2/iter={q['sum_m2']/it:.0f} us/iter: asm={q['asm']/it:.0f} piv={q['piv']/it:.0f} schur={q['schur']/it:.0f} store={q['store']/it:.0f}" + (f" (asm: zero+own A={q['asm_own']/it:.0f})" if "asm_own" in q else ""), flush=True)
         eng.close()
