@@ -659,6 +659,9 @@ namespace pe
         long long const ck1 = tm.clock();
         int const NW = tm.n_waves();
         constexpr int NB = 8;
+        // A bad pivot is reported once per front, after the block loop: nothing below branches on or indexes by matrix values,
+        // and the barriers inside the loop order LDS traffic only.
+        int bad = 0;
         for(int k0 = 0; k0 < p; k0 += NB)
         {
             int const kb = p - k0 < NB ? p - k0 : NB;
@@ -666,20 +669,17 @@ namespace pe
             {
                 // one wavefront owns the front (m <= 64): diagonal block, rows below it and columns right of it in ONE pass over
                 // registers, cross-lane traffic on v_readlane (tm.block_step)
-                int bad = 0;
-                tm.for_each_wave([&](int, int lane, int) { bad = tm.block_step(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, lane); });
-                if(tm.sync_or(bad)) return false;
+                tm.for_each_wave([&](int, int lane, int) { bad |= tm.block_step(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, lane); });
             }
             else
             {
                 // (a0) diagonal block, wavefront 0: LU of the kb x kb block in registers (tm.diag_lu8), L stored scaled
-                int bad = 0;
                 tm.for_each_wave(
                     [&](int w, int lane, int NL)
                     {
-                        if(w == 0) bad = tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
+                        if(w == 0) bad |= tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
                     });
-                if(tm.sync_or(bad)) return false;
+                tm.sync_lds();
                 // (a1) rows below the block (L) and columns right of it (U): one thread each; the 8 x 8 block and the
                 // thread's own row / column sit in registers, so the dependent chain is pure ALU
                 {
@@ -745,7 +745,7 @@ namespace pe
                     }
                 }
             }
-            tm.sync();
+            tm.sync_lds();
             // (b) trailing update of both panels, one 16 x 16 tile per wavefront at a time
             {
                 int const r0 = k0 + kb;
@@ -800,8 +800,9 @@ namespace pe
                         }
                     });
             }
-            tm.sync();
+            tm.sync_lds();
         }
+        if(tm.sync_or(bad)) return false;
         long long const ck2 = tm.clock();
         if(profile == 1 && V.prof && t0 == 0)
         {
