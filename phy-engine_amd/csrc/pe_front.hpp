@@ -687,6 +687,7 @@ namespace pe
                     int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
                     int const ncols = ncolL + u;              // plus every column of the U panel
                     int const ngc = fuse ? 1 : 0;             // plus the right-hand-side column
+                    auto const B8 = tm.blk_load(Lp + k0 + k0 * m, m, kb, t0 & 63);  // the factored block, one entry per lane
                     for(int q = t0; q < nrows + ncols + ngc; q += T)
                     {
                         double x[NB];
@@ -703,7 +704,7 @@ namespace pe
                                 {
                                     double ucol[NB];
     #pragma unroll
-                                    for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? Lp[(k0 + r) + (k0 + kk) * m] : 0.0;
+                                    for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? tm.blk_at(B8, r, kk) : 0.0;
                                     double const rdiag = tm.rcp(ucol[kk]);  // independent of the chain below: overlaps with it
                                     double acc = x[kk];
     #pragma unroll
@@ -730,7 +731,7 @@ namespace pe
                                 {
                                     double lrow[NB];
     #pragma unroll
-                                    for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? Lp[(k0 + kk) + (k0 + r) * m] : 0.0;
+                                    for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? tm.blk_at(B8, kk, r) : 0.0;
                                     double acc = x[kk];
     #pragma unroll
                                     for(int r = 0; r < NB; ++r)

@@ -85,6 +85,18 @@ namespace pe
             int const hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
             return __hiloint2double(hi, lo);
         }
+        // The factored 8 x 8 diagonal block held one entry per lane (lane l <-> row l&7, column l>>3); blk_at(r, c) broadcasts an
+        // entry by v_readlane: the solves against the block then need ONE LDS read per lane instead of one per triangle entry
+        struct Blk8
+        {
+            double e;
+        };
+        __device__ __forceinline__ Blk8 blk_load(double const* blk, int ld, int kb, int lane) const
+        {
+            int const r = lane & 7, c = lane >> 3;
+            return Blk8{(r < kb && c < kb) ? blk[r + c * ld] : (r == c ? 1.0 : 0.0)};
+        }
+        __device__ __forceinline__ double blk_at(Blk8 const& b, int r, int c) const { return bcast(b.e, r + 8 * c); }
         // One block step (kb <= 8 pivots from k0) of a front that ONE wavefront owns (m <= 64).
         // Rows: lane i holds row k0 + i of the block's columns in registers and the pivot row of step kk comes from lane kk by
         // v_readlane -- the LU of the diagonal block and the solve of the rows below it (x U11 = a) are the same elimination,

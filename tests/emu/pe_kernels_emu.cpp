@@ -29,6 +29,13 @@ namespace pe
         }
         int n_waves() const { return nw; }
         bool single_wave() const { return nw == 1; }
+        struct Blk8
+        {
+            double const* p;
+            int ld;
+        };
+        Blk8 blk_load(double const* blk, int ld, int, int) const { return Blk8{blk, ld}; }
+        double blk_at(Blk8 const& b, int r, int c) const { return b.p[r + c * b.ld]; }
         int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int) const
         {
             for(int kk = 0; kk < kb; ++kk)
