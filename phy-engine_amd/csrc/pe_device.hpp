@@ -101,6 +101,7 @@ namespace pe
         int const* f_cnp;            // per child edge: leading update rows of the child that are pivot rows of the parent
         int const* f_inv;
         int const *f_asm_ptr, *asm_slot, *asm_pos;
+        double* zero;  // one 0.0 in device memory: where the masked-out lanes of an unconditional gather point
         long long const *f_lptr, *f_uptr, *f_sptr;
         int const *row_src, *col_src;
         // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts

@@ -871,23 +871,38 @@ namespace pe
                             if(staged)
                             {
                                 // every child's metadata and inverse map come from LDS, every load from the children's
-                                // update matrices is unconditional: the loads of several children are in flight together
-#pragma unroll 4
-                                for(int q = 0; q < nch; ++q)
+                                // update matrices is unconditional (lanes without a contribution read a 0.0 parked in device
+                                // memory): the loads of several children are in flight together.  The first two children are
+                                // requested BEFORE the rank-p product and added after it, so their latency hides behind the MFMAs.
+                                auto pull = [&](int q)
                                 {
+                                    auto raw = tm.tile_zero();
                                     int const uc = cuc[q];
                                     double const* Sc = arena + csp[q];
                                     int const* inv = linv + q * u;
-                                    tm.tile_foreach(acc, lane,
+                                    tm.tile_foreach(raw, lane,
                                                     [&](int r, int c, double& v)
                                                     {
                                                         bool const in = r < mr && c < nc;
                                                         int const ci = in ? inv[i0 + r] : -1, cj = in ? inv[j0 + c] : -1;
-                                                        bool const hit = ci >= 0 && cj >= 0;
-                                                        double const sv = Sc[hit ? ci + cj * uc : 0];
-                                                        v += hit ? sv : 0.0;
+                                                        double const* src = (ci >= 0 && cj >= 0) ? Sc + (ci + cj * uc) : V.zero;
+                                                        v = *src;
                                                     });
+                                    return raw;
+                                };
+                                auto raw0 = tm.tile_zero(), raw1 = tm.tile_zero();
+                                if(nch > 0) raw0 = pull(0);
+                                if(nch > 1) raw1 = pull(1);
+                                tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
+                                tm.tile_add(acc, raw0);
+                                tm.tile_add(acc, raw1);
+                                for(int q = 2; q < nch; ++q)
+                                {
+                                    auto const rq = pull(q);
+                                    tm.tile_add(acc, rq);
                                 }
+                                tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
+                                continue;
                             }
                             else
                             {

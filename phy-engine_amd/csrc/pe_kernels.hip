@@ -242,6 +242,7 @@ namespace pe
             v4d v;
         };
         __device__ __forceinline__ Acc tile_zero() const { return Acc{v4d{0.0, 0.0, 0.0, 0.0}}; }
+        __device__ __forceinline__ void tile_add(Acc& a, Acc const& b) const { a.v += b.v; }
         __device__ __forceinline__ Acc tile_load(double const* C, int ldc, int mr, int nc, int lane) const
         {
             Acc a;

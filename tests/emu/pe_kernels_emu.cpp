@@ -102,6 +102,11 @@ namespace pe
                 for(double& x: r) x = 0.0;
             return a;
         }
+        void tile_add(Acc& a, Acc const& b) const
+        {
+            for(int r = 0; r < 16; ++r)
+                for(int c = 0; c < 16; ++c) a.v[r][c] += b.v[r][c];
+        }
         Acc tile_load(double const* C, int ldc, int mr, int nc, int) const
         {
             Acc a = tile_zero();
