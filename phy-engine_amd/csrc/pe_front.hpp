@@ -539,16 +539,45 @@ namespace pe
         if(e0 < e1) place(pos0, v0);
         for(int e = e0 + T; e < e1; e += T) place(V.asm_pos[e], a[V.asm_slot ? V.asm_slot[e] : e]);
         long long const cka = tm.clock();
+        // the first children's metadata (wavefront-uniform: scalar loads) is requested before the fence, off the path between
+        // the fence and the first loads from the children's update matrices
+        constexpr int PC = 4;
+        int pc_u[PC], pc_rows[PC];
+        long long pc_s[PC];
+#pragma unroll
+        for(int q = 0; q < PC; ++q)
+        {
+            int c = s;  // (no such child: this front's own entries, never used)
+            if(ch0 + q < ch1) c = V.f_child[ch0 + q];
+            pc_u[q] = V.f_u[c];
+            pc_s[q] = V.f_sptr[c];
+            pc_rows[q] = V.f_rows_ptr[c];
+        }
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
         if(ch1 > ch0) tm.sync();
         else
             tm.sync_lds();
         for(int ch = ch0; ch < ch1; ++ch)
         {
-            int const c = V.f_child[ch];
-            int const uc = V.f_u[c];
-            double const* Sc = arena + V.f_sptr[c];
-            int const* rel = V.f_rel + V.f_rows_ptr[c];
+            int uc, rows0;
+            long long sp;
+            {
+                int const k = ch - ch0;
+                if(k < PC)
+                {
+                    uc = pc_u[0], sp = pc_s[0], rows0 = pc_rows[0];
+#pragma unroll
+                    for(int q = 1; q < PC; ++q)
+                        if(k == q) uc = pc_u[q], sp = pc_s[q], rows0 = pc_rows[q];
+                }
+                else
+                {
+                    int const c = V.f_child[ch];
+                    uc = V.f_u[c], sp = V.f_sptr[c], rows0 = V.f_rows_ptr[c];
+                }
+            }
+            double const* Sc = arena + sp;
+            int const* rel = V.f_rel + rows0;
             float const rcp = 1.0f / static_cast<float>(uc);
             int const n = uc * uc;
             if(chain)
