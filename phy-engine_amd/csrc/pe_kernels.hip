@@ -439,13 +439,22 @@ namespace pe
     }
 
     template <int MINW>
-    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level)
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level, int nlev)
     {
+        // one workgroup per front of `level`; nlev > 1: a run of single-front levels (a chain at the top of the tree) handled by
+        // the same workgroup one after the other -- saves a launch per level where a launch is most of the level's time
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         HipTeam tm;
-        int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        for(int l = level; l < level + nlev; ++l)
+        {
+            int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
+            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            {
+                if(tm.tid() == 0) atomicOr(V.flags + b, 4);
+                return;
+            }
+        }
     }
 
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)
@@ -470,15 +479,20 @@ namespace pe
     }
 
     template <int MINW>
-    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_top(DevView V, int level, int backward)
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_top(DevView V, int level, int nlev, int backward)
     {
+        // levels level .. level + nlev - 1 (nlev > 1: single-front levels, see k_m2_factor_top); backward walks them downwards
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         HipTeam tm;
-        int const s = V.top_list[V.top_ptr[level] + static_cast<int>(blockIdx.x)];
-        if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
-        else
-            front_forward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
+        for(int i = 0; i < nlev; ++i)
+        {
+            int const l = backward ? level + nlev - 1 - i : level + i;
+            int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
+            if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
+            else
+                front_forward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
+        }
     }
 
     __global__ void __launch_bounds__(256) k_m2_finish(DevView V)
@@ -546,6 +560,21 @@ namespace pe
         }
         int const B = V.batch, T = V.n_waves * 64;
         int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
+        // runs of single-front top levels share a launch
+        auto run = [&](int l)
+        {
+            int n = 1;
+            if(V.top_cnt[l] == 1)
+                while(l + n < V.n_top_levels && V.top_cnt[l + n] == 1) ++n;
+            return n;
+        };
+        auto run_down = [&](int l)
+        {
+            int n = 1;
+            if(V.top_cnt[l] == 1)
+                while(l - n >= 0 && V.top_cnt[l - n] == 1) ++n;
+            return n;
+        };
         hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
         hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
         hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
@@ -555,15 +584,19 @@ namespace pe
             if(ev0) (void)hipEventRecord(ev0, st);
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
-            for(int l = 0; l < V.n_top_levels; ++l)
-                hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l);
+            for(int l = 0; l < V.n_top_levels; l += run(l)) hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
         }
         else
         {
             hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 0);
-            for(int l = 0; l < V.n_top_levels; ++l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 0);
+            for(int l = 0; l < V.n_top_levels; l += run(l)) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, run(l), 0);
         }
-        for(int l = V.n_top_levels - 1; l >= 0; --l) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, 1);
+        for(int l = V.n_top_levels - 1; l >= 0;)
+        {
+            int const n = run_down(l);
+            hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l - n + 1, n, 1);
+            l -= n;
+        }
         if(!do_factor && ev0) (void)hipEventRecord(ev0, st);
         hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 1);
         if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
