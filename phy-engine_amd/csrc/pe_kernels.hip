@@ -544,6 +544,15 @@ namespace pe
     }
 
     // one Newton iteration of every active instance in the split schedule: stamp -> LU -> solves -> Newton bits.
+    // workgroups per instance of the elementwise kernels (eval, stamp, winit, finish, companion): ~2048 rows each for large
+    // batches; few instances spread over more workgroups (these kernels are gathers: latency-bound at low occupancy)
+    static int grid_per_instance(DevView const& V)
+    {
+        int const by_rows = (V.rows + 2047) / 2048, fine = (V.rows + 255) / 256, want = 512 / (V.batch > 0 ? V.batch : 1);
+        int g = by_rows > (want < fine ? want : fine) ? by_rows : (want < fine ? want : fine);
+        return g < 1 ? 1 : (g > 64 ? 64 : g);
+    }
+
     // ev0 / ev1 (may be null): HIP events recorded around the dominant launch (k_m2_factor_parts, or the backward
     // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
     template <int MINW>
@@ -559,7 +568,7 @@ namespace pe
             if(e != hipSuccess) return e;
         }
         int const B = V.batch, T = V.n_waves * 64;
-        int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
+        int const G = grid_per_instance(V);
         // runs of single-front top levels share a launch
         auto run = [&](int l)
         {
@@ -611,7 +620,7 @@ namespace pe
 
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt)
     {
-        int const G = (V.rows + 2047) / 2048 > 0 ? ((V.rows + 2047) / 2048 < 32 ? (V.rows + 2047) / 2048 : 32) : 1;
+        int const G = grid_per_instance(V);
         hipLaunchKernelGGL(k_m2_companion, dim3(G, V.batch), dim3(256), 0, st, V, dt);
         return hipGetLastError();
     }
