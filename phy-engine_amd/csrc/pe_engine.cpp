@@ -292,7 +292,7 @@ namespace
         so.absorb_m = std::max(1, env_int("PHY_ENGINE_HIP_ABSORB_M", so.absorb_m));
         so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
         so.cut_factor = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_CUT_X10", static_cast<int>(so.cut_factor * 10.0)));
-        so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 48);
+        so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 64);  // (the triangular solves keep one pivot per lane)
         so.n_parts = std::clamp(env_int("PHY_ENGINE_HIP_PARTS", so.n_parts), 1, 64);
         if(env_int("PHY_ENGINE_HIP_SPLIT", -1) == 0) so.n_parts = 1;  // the resident kernel handles one part per instance
         so.part_cut = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_PART_CUT_X10", static_cast<int>(so.part_cut * 10.0)));
