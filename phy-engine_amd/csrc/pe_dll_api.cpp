@@ -142,6 +142,28 @@ namespace
             case 207: out = add_model(nl, XNOR{}); return true;
             case 208: out = add_model(nl, NAND{}); return true;
             case 209: out = add_model(nl, NOR{}); return true;
+            // ---- digital blocks (dll_api.h:110-124): host event queue only
+            case 210: out = add_model(nl, TRI{}); return true;
+            case 211: out = add_model(nl, IMP{}); return true;
+            case 212: out = add_model(nl, NIMP{}); return true;
+            case 220: out = add_model(nl, HALF_ADDER{}); return true;
+            case 221: out = add_model(nl, FULL_ADDER{}); return true;
+            case 222: out = add_model(nl, HALF_SUB{}); return true;
+            case 223: out = add_model(nl, FULL_SUB{}); return true;
+            case 224: out = add_model(nl, MUL2{}); return true;
+            case 225: out = add_model(nl, DFF{}); return true;
+            case 226: out = add_model(nl, TFF{}); return true;
+            case 227: out = add_model(nl, T_BAR_FF{}); return true;
+            case 228: out = add_model(nl, JKFF{}); return true;
+            case 229:
+            {
+                // COUNTER4{init_value 0..15}
+                double const v = take();
+                COUNTER4 ctr{};
+                ctr.value = static_cast<::std::uint8_t>(v < 0.0 ? 0u : (v > 15.0 ? 15u : static_cast<unsigned>(v)));
+                out = add_model(nl, ctr);
+                return true;
+            }
             case 50:
             case 51:
             {

@@ -188,10 +188,10 @@ namespace phy_engine::model
     }
 
     // two-input gates (digital/logical/and.h, or.h, xor.h, xnor.h, nand.h, nor.h): same input sampling, output = op(a, b)
-    template <int OP>  // 0 AND, 1 OR, 2 XOR, 3 XNOR, 4 NAND, 5 NOR
+    template <int OP>  // 0 AND, 1 OR, 2 XOR, 3 XNOR, 4 NAND, 5 NOR, 6 IMP (~a | b, implication.h:326), 7 NIMP (a & ~b, non_implication.h:326)
     struct gate2
     {
-        inline static constexpr ::fast_io::u8string_view names[6] = {u8"AND", u8"OR", u8"XOR", u8"XNOR", u8"NAND", u8"NOR"};
+        inline static constexpr ::fast_io::u8string_view names[8] = {u8"AND", u8"OR", u8"XOR", u8"XNOR", u8"NAND", u8"NOR", u8"IMP", u8"NIMP"};
         inline static constexpr ::fast_io::u8string_view model_name{names[OP]};
         inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
         inline static constexpr model_device_type device_type{model_device_type::digital};
@@ -207,6 +207,8 @@ namespace phy_engine::model
     using XNOR = gate2<3>;
     using NAND = gate2<4>;
     using NOR = gate2<5>;
+    using IMP = gate2<6>;
+    using NIMP = gate2<7>;
     template <int OP>
     inline pin_view generate_pin_view_define(model_reserve_type_t<gate2<OP>>, gate2<OP>& g) noexcept { return {g.pins, 3}; }
     template <int OP>
@@ -230,8 +232,12 @@ namespace phy_engine::model
             r = ~(va ^ vb);
         else if constexpr(OP == 4)
             r = ~(va & vb);
-        else
+        else if constexpr(OP == 5)
             r = ~(va | vb);
+        else if constexpr(OP == 6)
+            r = ~va | vb;
+        else
+            r = va & ~vb;
         return details::drive_output(g, o, r, table);
     }
 
@@ -324,6 +330,386 @@ namespace phy_engine::model
         return details::drive_output(g, o, g.outputA, table);
     }
 
+
+    // ------------------------------------------------------------------ blocks (digital/combinational/*.h, logical/tri_state.h)
+    // These read their inputs without the setup / hold state machine of the gates: a digital node's state with Z taken as X,
+    // an analog node by plain thresholds (e.g. half_adder.h:41-54); outputs go to digital nodes when they differ from what the
+    // block wrote last, and the FIRST output that sits on an analog node becomes the ideal source of the next analyze().
+    namespace details
+    {
+        template <typename G>
+        inline digital_node_statement_t read_level(G const& g, node_t* n) noexcept
+        {
+            using s = digital_node_statement_t;
+            if(n->num_of_analog_node == 0)
+            {
+                auto const st = n->node_information.dn.state;
+                return st == s::high_impedence_state ? s::indeterminate_state : st;
+            }
+            double const v = n->node_information.an.voltage.real();
+            if(v >= g.Hl) return s::true_state;
+            if(v <= g.Ll) return s::false_state;
+            return s::indeterminate_state;
+        }
+        template <typename G>
+        inline ::phy_engine::digital::need_operate_analog_node_t level_of(G const& g, node_t* n, digital_node_statement_t v) noexcept
+        {
+            return {v == digital_node_statement_t::true_state ? g.Hl : g.Ll, n};
+        }
+        inline digital_node_statement_t toggled(digital_node_statement_t q) noexcept
+        {
+            // t_ff.h:61: static_cast<state>(!static_cast<bool>(q)) -- X and Z toggle to L
+            return static_cast<digital_node_statement_t>(!static_cast<bool>(q));
+        }
+        inline bool settled(digital_node_statement_t v) noexcept { return v == digital_node_statement_t::false_state || v == digital_node_statement_t::true_state; }
+    }  // namespace details
+
+    // tri-state buffer (logical/tri_state.h:77-131): disabled -> Z on a digital output (queued every time), nothing on an analog one
+    struct TRI
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"TRI"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"TRI"};
+        pin pins[3]{{{u8"i"}}, {{u8"en"}}, {{u8"o"}}};
+        double Ll{0.0}, Hl{5.0};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<TRI>, TRI& t) noexcept { return {t.pins, 3}; }
+    inline bool set_attribute_define(model_reserve_type_t<TRI>, TRI& t, ::std::size_t n, variant vi) noexcept
+    {
+        if(vi.type != variant_type::d || n > 1) return false;
+        (n == 0 ? t.Ll : t.Hl) = vi.d;
+        return true;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<TRI>, TRI const& t, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n > 1) return r;
+        r.d = n == 0 ? t.Ll : t.Hl;
+        r.type = variant_type::d;
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<TRI>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"Ll"} : n == 1 ? ::fast_io::u8string_view{u8"Hl"} : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<TRI>, TRI& t,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        auto* i = t.pins[0].nodes;
+        auto* en = t.pins[1].nodes;
+        auto* o = t.pins[2].nodes;
+        if(!i || !en || !o) return {};
+        bool const enabled = en->num_of_analog_node != 0 ? en->node_information.an.voltage.real() >= t.Hl : en->node_information.dn.state == s::true_state;
+        if(!enabled)
+        {
+            if(o->num_of_analog_node == 0)
+            {
+                o->node_information.dn.state = s::high_impedence_state;
+                table.tables.insert(o);
+            }
+            return {};
+        }
+        s in{};
+        if(i->num_of_analog_node != 0)
+        {
+            double const v = i->node_information.an.voltage.real();
+            in = v >= t.Hl ? s::true_state : (v <= t.Ll ? s::false_state : s::indeterminate_state);
+        }
+        else
+            in = i->node_information.dn.state;
+        if(o->num_of_analog_node != 0) return details::level_of(t, o, in);
+        o->node_information.dn.state = in;
+        table.tables.insert(o);
+        return {};
+    }
+
+    // adders / subtractors / 2 x 2 multiplier: NIN inputs, NOUT outputs, any unknown input makes every output X
+    template <int KIND>  // 0 HALF_ADDER, 1 FULL_ADDER, 2 HALF_SUBTRACTOR, 3 FULL_SUBTRACTOR, 4 MUL2
+    struct arith_block
+    {
+        inline static constexpr ::fast_io::u8string_view names[5] = {u8"HALF_ADDER", u8"FULL_ADDER", u8"HALF_SUB", u8"FULL_SUB", u8"MUL2"};
+        inline static constexpr ::fast_io::u8string_view ids[5] = {u8"HA", u8"FA", u8"HS", u8"FS", u8"M2"};
+        inline static constexpr int n_in = KIND == 0 || KIND == 2 ? 2 : (KIND == 4 ? 4 : 3);
+        inline static constexpr int n_out = KIND == 4 ? 4 : 2;
+        inline static constexpr ::fast_io::u8string_view model_name{names[KIND]};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{ids[KIND]};
+        pin pins[n_in + n_out]{};
+        double Ll{0.0}, Hl{5.0};
+        digital_node_statement_t last[n_out]{digital_node_statement_t::X, digital_node_statement_t::X};
+        constexpr arith_block() noexcept
+        {
+            constexpr char8_t const* pn[5][8] = {{u8"ia", u8"ib", u8"s", u8"c"},
+                                                 {u8"ia", u8"ib", u8"cin", u8"s", u8"cout"},
+                                                 {u8"ia", u8"ib", u8"d", u8"b"},
+                                                 {u8"ia", u8"ib", u8"bin", u8"d", u8"bout"},
+                                                 {u8"a0", u8"a1", u8"b0", u8"b1", u8"p0", u8"p1", u8"p2", u8"p3"}};
+            for(int k = 0; k < n_in + n_out; ++k) pins[k].name = ::fast_io::u8string_view{pn[KIND][k]};
+            for(int k = 0; k < n_out; ++k) last[k] = digital_node_statement_t::X;
+        }
+    };
+    using HALF_ADDER = arith_block<0>;
+    using FULL_ADDER = arith_block<1>;
+    using HALF_SUB = arith_block<2>;
+    using FULL_SUB = arith_block<3>;
+    using MUL2 = arith_block<4>;
+    template <int KIND>
+    inline pin_view generate_pin_view_define(model_reserve_type_t<arith_block<KIND>>, arith_block<KIND>& g) noexcept
+    {
+        return {g.pins, static_cast<::std::size_t>(arith_block<KIND>::n_in + arith_block<KIND>::n_out)};
+    }
+    template <int KIND>
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<arith_block<KIND>>, arith_block<KIND>& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        constexpr int NI = arith_block<KIND>::n_in, NO = arith_block<KIND>::n_out;
+        for(int k = 0; k < NI + NO; ++k)
+            if(!g.pins[k].nodes) return {};
+        s in[4]{};
+        bool unknown = false;
+        for(int k = 0; k < NI; ++k)
+        {
+            in[k] = details::read_level(g, g.pins[k].nodes);
+            unknown = unknown || in[k] == s::indeterminate_state;
+        }
+        s out[4]{s::indeterminate_state, s::indeterminate_state, s::indeterminate_state, s::indeterminate_state};
+        if(!unknown)
+        {
+            if constexpr(KIND == 0) out[0] = in[0] ^ in[1], out[1] = in[0] & in[1];                                      // half_adder.h:58-59
+            else if constexpr(KIND == 1)
+                out[0] = in[0] ^ in[1] ^ in[2], out[1] = (in[0] & in[1]) | (in[0] & in[2]) | (in[1] & in[2]);             // full_adder.h:62-63
+            else if constexpr(KIND == 2)
+                out[0] = in[0] ^ in[1], out[1] = ~in[0] & in[1];                                                          // half_subtractor.h:72-73
+            else if constexpr(KIND == 3)
+                out[0] = in[0] ^ in[1] ^ in[2], out[1] = (~in[0] & in[1]) | (~in[0] & in[2]) | (in[1] & in[2]);           // full_subtractor.h:75-76
+            else
+            {
+                // mul2.h:81-88: inputs a0 a1 b0 b1
+                auto const t1 = in[0] & in[3], t2 = in[1] & in[2], c1 = t1 & t2, t3 = in[1] & in[3];
+                out[0] = in[0] & in[2];
+                out[1] = t1 ^ t2;
+                out[2] = t3 ^ c1;
+                out[3] = t3 & c1;
+            }
+        }
+        if constexpr(KIND == 4)
+        {
+            // mul2.h:98-121: output by output; the first analog one ends the update
+            for(int k = 0; k < NO; ++k)
+            {
+                auto* n = g.pins[NI + k].nodes;
+                if(n->num_of_analog_node != 0) return details::level_of(g, n, out[k]);
+                if(g.last[k] != out[k])
+                {
+                    g.last[k] = out[k];
+                    n->node_information.dn.state = out[k];
+                    table.tables.insert(n);
+                }
+            }
+            return {};
+        }
+        else
+        {
+            // half_adder.h:63-104: digital outputs first, then the first analog one
+            for(int k = 0; k < NO; ++k)
+            {
+                auto* n = g.pins[NI + k].nodes;
+                if(n->num_of_analog_node == 0 && g.last[k] != out[k])
+                {
+                    g.last[k] = out[k];
+                    n->node_information.dn.state = out[k];
+                    table.tables.insert(n);
+                }
+            }
+            for(int k = 0; k < NO; ++k)
+            {
+                auto* n = g.pins[NI + k].nodes;
+                if(n->num_of_analog_node != 0) return details::level_of(g, n, out[k]);
+            }
+            return {};
+        }
+    }
+
+    // edge-triggered flip-flops (d_ff.h, t_ff.h, t_bar_ff.h, jk_ff.h): rising edge = last settled clock level L, now H
+    template <int KIND>  // 0 DFF (d clk q), 1 TFF (t clk q), 2 T_BAR_FF (t_bar clk q), 3 JKFF (j k clk q)
+    struct flip_flop
+    {
+        inline static constexpr ::fast_io::u8string_view names[4] = {u8"DFF", u8"TFF", u8"T_BAR_FF", u8"JKFF"};
+        inline static constexpr int n_pins = KIND == 3 ? 4 : 3;
+        inline static constexpr ::fast_io::u8string_view model_name{names[KIND]};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{names[KIND]};
+        pin pins[n_pins]{};
+        double Ll{0.0}, Hl{5.0};
+        digital_node_statement_t q{digital_node_statement_t::false_state};
+        digital_node_statement_t last_clk{digital_node_statement_t::false_state};
+        constexpr flip_flop() noexcept
+        {
+            constexpr char8_t const* pn[4][4] = {{u8"d", u8"clk", u8"q"}, {u8"t", u8"clk", u8"q"}, {u8"t_bar", u8"clk", u8"q"}, {u8"j", u8"k", u8"clk", u8"q"}};
+            for(int k = 0; k < n_pins; ++k) pins[k].name = ::fast_io::u8string_view{pn[KIND][k]};
+        }
+    };
+    using DFF = flip_flop<0>;
+    using TFF = flip_flop<1>;
+    using T_BAR_FF = flip_flop<2>;
+    using JKFF = flip_flop<3>;
+    template <int KIND>
+    inline pin_view generate_pin_view_define(model_reserve_type_t<flip_flop<KIND>>, flip_flop<KIND>& g) noexcept
+    {
+        return {g.pins, static_cast<::std::size_t>(flip_flop<KIND>::n_pins)};
+    }
+    template <int KIND>
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<flip_flop<KIND>>, flip_flop<KIND>& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        constexpr int NP = flip_flop<KIND>::n_pins;
+        for(int k = 0; k < NP; ++k)
+            if(!g.pins[k].nodes) return {};
+        auto const a = details::read_level(g, g.pins[0].nodes);
+        auto const b = KIND == 3 ? details::read_level(g, g.pins[1].nodes) : s::false_state;
+        auto const clk = details::read_level(g, g.pins[NP - 2].nodes);
+        auto* nq = g.pins[NP - 1].nodes;
+        if(g.last_clk == s::false_state && clk == s::true_state)
+        {
+            if constexpr(KIND == 0) g.q = a;                                           // d_ff.h:62
+            else if constexpr(KIND == 1)
+            {
+                if(a == s::true_state) g.q = details::toggled(g.q);                    // t_ff.h:59-66
+                else if(a == s::indeterminate_state)
+                    g.q = s::indeterminate_state;
+            }
+            else if constexpr(KIND == 2)
+            {
+                if(a == s::false_state) g.q = details::toggled(g.q);                   // t_bar_ff.h: active-low toggle
+                else if(a == s::indeterminate_state)
+                    g.q = s::indeterminate_state;
+            }
+            else
+            {
+                if(a == s::true_state && b == s::false_state) g.q = s::true_state;     // jk_ff.h:62-79
+                else if(a == s::false_state && b == s::true_state)
+                    g.q = s::false_state;
+                else if(a == s::true_state && b == s::true_state)
+                    g.q = details::toggled(g.q);
+                else if(a == s::indeterminate_state || b == s::indeterminate_state)
+                    g.q = s::indeterminate_state;
+            }
+        }
+        if(details::settled(clk)) g.last_clk = clk;
+        if(nq->num_of_analog_node != 0) return details::level_of(g, nq, g.q);
+        if(nq->node_information.dn.state != g.q)
+        {
+            nq->node_information.dn.state = g.q;
+            table.tables.insert(nq);
+        }
+        return {};
+    }
+
+    // 4-bit counter (combinational/counter4.h): pins q3 q2 q1 q0 clk en (en missing / Z = enabled); attributes value, unknown
+    struct COUNTER4
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"COUNTER4"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"COUNTER4"};
+        pin pins[6]{{{u8"q3"}}, {{u8"q2"}}, {{u8"q1"}}, {{u8"q0"}}, {{u8"clk"}}, {{u8"en"}}};
+        double Ll{0.0}, Hl{5.0};
+        ::std::uint8_t value{};
+        bool unknown{};
+        digital_node_statement_t last_clk{digital_node_statement_t::false_state};
+        ::std::uint8_t last_value{0xFF};
+        bool last_unknown{true};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<COUNTER4>, COUNTER4& g) noexcept { return {g.pins, 6}; }
+    inline bool set_attribute_define(model_reserve_type_t<COUNTER4>, COUNTER4& g, ::std::size_t n, variant vi) noexcept
+    {
+        if(n == 0 && vi.type == variant_type::ui8)
+        {
+            g.value = static_cast<::std::uint8_t>(vi.ui8 & 0x0F);
+            g.unknown = false;
+            return true;
+        }
+        if(n == 1 && vi.type == variant_type::boolean)
+        {
+            g.unknown = vi.boolean;
+            return true;
+        }
+        return false;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<COUNTER4>, COUNTER4 const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n == 0)
+        {
+            r.ui8 = static_cast<::std::uint_least8_t>(g.value & 0x0F);
+            r.type = variant_type::ui8;
+        }
+        else if(n == 1)
+        {
+            r.boolean = g.unknown;
+            r.type = variant_type::boolean;
+        }
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<COUNTER4>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"value"} : n == 1 ? ::fast_io::u8string_view{u8"unknown"} : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<COUNTER4>, COUNTER4& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        auto* n_clk = g.pins[4].nodes;
+        auto* n_en = g.pins[5].nodes;
+        if(!n_clk) return {};
+        auto const clk = details::read_level(g, n_clk);
+        // counter4.h:117-119: the enable keeps Z on a digital node (-> enabled); an analog node goes through the thresholds
+        s en = !n_en ? s::high_impedence_state : (n_en->num_of_analog_node == 0 ? n_en->node_information.dn.state : details::read_level(g, n_en));
+        if(en == s::high_impedence_state) en = s::true_state;
+        if(g.last_clk == s::false_state && clk == s::true_state)
+        {
+            if(en == s::true_state)
+            {
+                if(!g.unknown) g.value = static_cast<::std::uint8_t>((g.value + 1u) & 0x0F);
+            }
+            else if(en != s::false_state)
+                g.unknown = true;
+        }
+        if(details::settled(clk)) g.last_clk = clk;
+        ::phy_engine::digital::need_operate_analog_node_t drive{};
+        for(int pin = 0; pin < 4; ++pin)
+        {
+            auto* nq = g.pins[pin].nodes;
+            if(!nq) continue;
+            s const out = g.unknown ? s::indeterminate_state : (((g.value >> static_cast<unsigned>(3 - pin)) & 1u) ? s::true_state : s::false_state);
+            if(nq->num_of_analog_node == 0)
+            {
+                if(nq->node_information.dn.state != out)
+                {
+                    nq->node_information.dn.state = out;
+                    table.tables.insert(nq);
+                }
+            }
+            else if(drive.need_to_operate_analog_node == nullptr)
+                drive = details::level_of(g, nq, out);
+        }
+        g.last_value = g.value;
+        g.last_unknown = g.unknown;
+        return drive;
+    }
+
     static_assert(defines::is_valid_digital_model<comparator> && defines::is_valid_digital_model<NOT> && defines::is_valid_digital_model<AND> &&
-                  defines::is_valid_digital_model<OUTPUT> && defines::is_valid_digital_model<INPUT>);
+                  defines::is_valid_digital_model<OUTPUT> && defines::is_valid_digital_model<INPUT> && defines::is_valid_digital_model<TRI> &&
+                  defines::is_valid_digital_model<FULL_ADDER> && defines::is_valid_digital_model<MUL2> && defines::is_valid_digital_model<JKFF> &&
+                  defines::is_valid_digital_model<COUNTER4>);
 }  // namespace phy_engine::model

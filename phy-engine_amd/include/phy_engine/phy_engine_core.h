@@ -252,7 +252,13 @@ namespace phy_engine
         {
             union
             {
+                ::std::int_least8_t i8;
+                ::std::int_least16_t i16;
+                ::std::int_least32_t i32;
                 ::std::int_least64_t i64;
+                ::std::uint_least8_t ui8;
+                ::std::uint_least16_t ui16;
+                ::std::uint_least32_t ui32;
                 ::std::uint_least64_t ui64{};
                 bool boolean;
                 float f;

@@ -139,9 +139,20 @@ def run_case(name):
     return name, meta["rows"], meta["fail_step"], meta.get("analyze_bit_equal")
 
 
+# goldens that are the plain output of a reference-linked program (oracle/Makefile): name -> (binary, file)
+PROGRAMS = {"adc": ("ref_adc", "adc_c4.json"), "digital": ("ref_digital", "digital_blocks.json")}
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES)
     os.makedirs(GOLD, exist_ok=True)
+    for n in [n for n in names if n in PROGRAMS]:
+        exe, fn = PROGRAMS[n]
+        out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe)], capture_output=True, text=True, check=True).stdout
+        json.loads(out)
+        open(os.path.join(GOLD, fn), "w").write(out)
+        print((n, fn, len(out)), flush=True)
+    names = [n for n in names if n not in PROGRAMS]
     with cf.ThreadPoolExecutor(max_workers=6) as ex:
         for r in ex.map(run_case, names):
             print(r, flush=True)

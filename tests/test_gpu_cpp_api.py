@@ -8,7 +8,7 @@ exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64).  Each mi
   dll_smoke       test/0008.dll/dll_main_smoke.cpp
   linear_models   the known answers of test/0005.models/{vccs_dc,vcvs_gain,cccs_dc,ccvs_dc,op_amp_follower,transformer_ratio,
                   transformer_center_tap_ratio,switch_r_open,generator_dc,coupled_inductors_TR,relay_hysteresis}.cpp
-  dll_elements / transistors / dll_mixed_signal   the loader's element codes 7-23, 50-53, 19 + 200-209 (dll_api.h:51-135)
+  dll_elements / transistors / dll_mixed_signal / dll_digital_blocks   the loader's element codes 7-23, 50-53, 19 + 200-212, 220-229 (dll_api.h:51-135)
 The same programs also run on the CPU against the host emulation of the kernels (tests/emu) to check the host-side logic.
 """
 import os
@@ -19,7 +19,7 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass"]  # adc_flash: checked against the golden below
+TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")
