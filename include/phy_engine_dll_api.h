@@ -10,8 +10,9 @@
  * 52/53 level-1 N/PMOSFET{Kp,lambda,Vth}.  Every analysis runs on the MI355X through include/pe_hip.h.  Other element codes
  * Mixed-signal: 19 comparator{Ll,Hl}, 200 INPUT{state}, 201 OUTPUT, 202 OR, 203 YES, 204 AND, 205 NOT, 206 XOR, 207 XNOR, 208 NAND,
  * 209 NOR, 210 TRI, 211 IMP, 212 NIMP, 220 HALF_ADDER, 221 FULL_ADDER, 222 HALF_SUB, 223 FULL_SUB, 224 MUL2, 225 DFF, 226 TFF,
- * 227 T_BAR_FF, 228 JKFF, 229 COUNTER4{init_value} (event logic on the host, circuit_digital_clk).  Other element codes (BSIM3,
- * 230-233 random generator / 8-bit input / 8-bit display / Schmitt trigger, Verilog 300-301) are rejected.
+ * 227 T_BAR_FF, 228 JKFF, 229 COUNTER4{init_value}, 230 RANDOM_GENERATOR4{init_state}, 231 EIGHT_BIT_INPUT{value},
+ * 232 EIGHT_BIT_DISPLAY, 233 SCHMITT_TRIGGER{Vth_low,Vth_high,inverted,Ll,Hl} (event logic on the host, circuit_digital_clk).
+ * Other element codes (BSIM3 = 24, Verilog 300-301 through create_circuit_ex) are rejected.
  */
 #ifndef PHY_ENGINE_DLL_API_SUBSET_H
 #define PHY_ENGINE_DLL_API_SUBSET_H

@@ -164,6 +164,37 @@ namespace
                 out = add_model(nl, ctr);
                 return true;
             }
+            case 230:
+            {
+                // RANDOM_GENERATOR4{init_state 0..15}
+                double const v = take();
+                RANDOM_GENERATOR4 g{};
+                g.state = static_cast<::std::uint8_t>(v < 0.0 ? 0u : (v > 15.0 ? 15u : static_cast<unsigned>(v)));
+                out = add_model(nl, g);
+                return true;
+            }
+            case 231:
+            {
+                // EIGHT_BIT_INPUT{value 0..255}
+                double const v = take();
+                EIGHT_BIT_INPUT g{};
+                g.value = static_cast<::std::uint8_t>(v < 0.0 ? 0u : (v > 255.0 ? 255u : static_cast<unsigned>(v)));
+                out = add_model(nl, g);
+                return true;
+            }
+            case 232: out = add_model(nl, EIGHT_BIT_DISPLAY{}); return true;
+            case 233:
+            {
+                // SCHMITT_TRIGGER{Vth_low, Vth_high, inverted, Ll, Hl}
+                SCHMITT_TRIGGER g{};
+                g.Vth_low = take();
+                g.Vth_high = take();
+                g.inverted = take() != 0.0;
+                g.Ll = take();
+                g.Hl = take();
+                out = add_model(nl, g);
+                return true;
+            }
             case 50:
             case 51:
             {

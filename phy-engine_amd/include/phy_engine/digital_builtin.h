@@ -708,8 +708,392 @@ namespace phy_engine::model
         return drive;
     }
 
+    // D latch (combinational/d_latch.h): pins d en q; en X -> q X, en H -> q = d, en L holds; q starts X
+    struct DLATCH
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"DLATCH"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"DLATCH"};
+        pin pins[3]{{{u8"d"}}, {{u8"en"}}, {{u8"q"}}};
+        double Ll{0.0}, Hl{5.0};
+        digital_node_statement_t q{digital_node_statement_t::indeterminate_state};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<DLATCH>, DLATCH& g) noexcept { return {g.pins, 3}; }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<DLATCH>, DLATCH& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        auto* nq = g.pins[2].nodes;
+        if(!g.pins[0].nodes || !g.pins[1].nodes || !nq) return {};
+        auto const d = details::read_level(g, g.pins[0].nodes);
+        auto const en = details::read_level(g, g.pins[1].nodes);
+        if(en == s::indeterminate_state) g.q = s::indeterminate_state;
+        else if(en == s::true_state)
+            g.q = d;
+        if(nq->num_of_analog_node != 0) return details::level_of(g, nq, g.q);
+        if(nq->node_information.dn.state != g.q)
+        {
+            nq->node_information.dn.state = g.q;
+            table.tables.insert(nq);
+        }
+        return {};
+    }
+
+    // D flip-flop with asynchronous active-low reset (combinational/d_ff_arstn.h): pins d clk arst_n q; reset X -> q X, reset L -> reset_value
+    struct DFF_ARSTN
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"DFF_ARSTN"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"DFF_ARSTN"};
+        pin pins[4]{{{u8"d"}}, {{u8"clk"}}, {{u8"arst_n"}}, {{u8"q"}}};
+        double Ll{0.0}, Hl{5.0};
+        digital_node_statement_t q{digital_node_statement_t::false_state};
+        digital_node_statement_t reset_value{digital_node_statement_t::false_state};
+        digital_node_statement_t last_clk{digital_node_statement_t::false_state};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<DFF_ARSTN>, DFF_ARSTN& g) noexcept { return {g.pins, 4}; }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<DFF_ARSTN>, DFF_ARSTN& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        for(auto& p: g.pins)
+            if(!p.nodes) return {};
+        auto const d = details::read_level(g, g.pins[0].nodes);
+        auto const clk = details::read_level(g, g.pins[1].nodes);
+        auto const rst = details::read_level(g, g.pins[2].nodes);
+        auto* nq = g.pins[3].nodes;
+        if(rst == s::indeterminate_state) g.q = s::indeterminate_state;
+        else if(rst == s::false_state)
+            g.q = g.reset_value;
+        else if(g.last_clk == s::false_state && clk == s::true_state)
+            g.q = d;
+        if(details::settled(clk)) g.last_clk = clk;
+        if(nq->num_of_analog_node != 0) return details::level_of(g, nq, g.q);
+        if(nq->node_information.dn.state != g.q)
+        {
+            nq->node_information.dn.state = g.q;
+            table.tables.insert(nq);
+        }
+        return {};
+    }
+
+    // 4-bit pseudo-random generator (combinational/random_generator4.h): pins q3 q2 q1 q0 clk reset_n; shift register with
+    // feedback (b3 ^ b2) ^ 1; reset dominates; attributes state, unknown
+    struct RANDOM_GENERATOR4
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"RANDOM_GENERATOR4"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"RANDOM_GENERATOR4"};
+        pin pins[6]{{{u8"q3"}}, {{u8"q2"}}, {{u8"q1"}}, {{u8"q0"}}, {{u8"clk"}}, {{u8"reset_n"}}};
+        double Ll{0.0}, Hl{5.0};
+        ::std::uint8_t state{1u};
+        bool unknown{};
+        digital_node_statement_t last_clk{digital_node_statement_t::false_state};
+        ::std::uint8_t last_state{0xFF};
+        bool last_unknown{true};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<RANDOM_GENERATOR4>, RANDOM_GENERATOR4& g) noexcept { return {g.pins, 6}; }
+    inline bool set_attribute_define(model_reserve_type_t<RANDOM_GENERATOR4>, RANDOM_GENERATOR4& g, ::std::size_t n, variant vi) noexcept
+    {
+        if(n == 0 && vi.type == variant_type::ui8)
+        {
+            g.state = static_cast<::std::uint8_t>(vi.ui8 & 0x0F);
+            g.unknown = false;
+            return true;
+        }
+        if(n == 1 && vi.type == variant_type::boolean)
+        {
+            g.unknown = vi.boolean;
+            return true;
+        }
+        return false;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<RANDOM_GENERATOR4>, RANDOM_GENERATOR4 const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n == 0)
+        {
+            r.ui8 = static_cast<::std::uint_least8_t>(g.state & 0x0F);
+            r.type = variant_type::ui8;
+        }
+        else if(n == 1)
+        {
+            r.boolean = g.unknown;
+            r.type = variant_type::boolean;
+        }
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<RANDOM_GENERATOR4>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"state"} : n == 1 ? ::fast_io::u8string_view{u8"unknown"} : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<RANDOM_GENERATOR4>, RANDOM_GENERATOR4& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        auto* n_clk = g.pins[4].nodes;
+        auto* n_rst = g.pins[5].nodes;
+        if(!n_clk) return {};
+        auto const clk = details::read_level(g, n_clk);
+        s rst = !n_rst ? s::high_impedence_state : (n_rst->num_of_analog_node == 0 ? n_rst->node_information.dn.state : details::read_level(g, n_rst));
+        if(rst == s::high_impedence_state) rst = s::true_state;
+        if(rst == s::false_state)
+        {
+            g.state = 0u;
+            g.unknown = false;
+        }
+        else if(rst == s::indeterminate_state)
+            g.unknown = true;
+        else if(g.last_clk == s::false_state && clk == s::true_state)
+        {
+            if(!g.unknown)
+            {
+                bool const b3 = ((g.state >> 3u) & 1u) != 0u, b2 = ((g.state >> 2u) & 1u) != 0u;
+                bool const feedback = (b3 ^ b2) ^ true;  // random_generator4.h:118-122: the constant keeps it out of the all-zero lock
+                g.state = static_cast<::std::uint8_t>(((g.state << 1u) & 0x0E) | static_cast<::std::uint8_t>(feedback));
+            }
+        }
+        if(details::settled(clk)) g.last_clk = clk;
+        ::phy_engine::digital::need_operate_analog_node_t drive{};
+        for(int pin = 0; pin < 4; ++pin)
+        {
+            auto* nq = g.pins[pin].nodes;
+            if(!nq) continue;
+            s const out = g.unknown ? s::indeterminate_state : (((g.state >> static_cast<unsigned>(3 - pin)) & 1u) ? s::true_state : s::false_state);
+            if(nq->num_of_analog_node == 0)
+            {
+                if(nq->node_information.dn.state != out)
+                {
+                    nq->node_information.dn.state = out;
+                    table.tables.insert(nq);
+                }
+            }
+            else if(drive.need_to_operate_analog_node == nullptr)
+                drive = details::level_of(g, nq, out);
+        }
+        g.last_state = g.state;
+        g.last_unknown = g.unknown;
+        return drive;
+    }
+
+    // 8-bit input (logical/eight_bit_input.h): pins b7..b0, drives attribute 0 (value) before every clock; digital pins are
+    // rewritten only when the value changed since the last tick
+    struct EIGHT_BIT_INPUT
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"EIGHT_BIT_INPUT"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::before_all_clk};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"EIGHT_BIT_INPUT"};
+        pin pins[8]{{{u8"b7"}}, {{u8"b6"}}, {{u8"b5"}}, {{u8"b4"}}, {{u8"b3"}}, {{u8"b2"}}, {{u8"b1"}}, {{u8"b0"}}};
+        double Ll{0.0}, Hl{5.0};
+        ::std::uint8_t value{};
+        ::std::uint8_t last_value{0xFF};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<EIGHT_BIT_INPUT>, EIGHT_BIT_INPUT& g) noexcept { return {g.pins, 8}; }
+    inline bool set_attribute_define(model_reserve_type_t<EIGHT_BIT_INPUT>, EIGHT_BIT_INPUT& g, ::std::size_t n, variant vi) noexcept
+    {
+        if(n != 0 || vi.type != variant_type::ui8) return false;
+        g.value = static_cast<::std::uint8_t>(vi.ui8);
+        return true;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<EIGHT_BIT_INPUT>, EIGHT_BIT_INPUT const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n != 0) return r;
+        r.ui8 = g.value;
+        r.type = variant_type::ui8;
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<EIGHT_BIT_INPUT>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"value"} : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<EIGHT_BIT_INPUT>, EIGHT_BIT_INPUT& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        bool const changed = g.last_value != g.value;
+        ::phy_engine::digital::need_operate_analog_node_t drive{};
+        for(int pin = 0; pin < 8; ++pin)
+        {
+            auto* n = g.pins[pin].nodes;
+            if(!n) continue;
+            s const out = ((g.value >> static_cast<unsigned>(7 - pin)) & 1u) ? s::true_state : s::false_state;
+            if(n->num_of_analog_node == 0)
+            {
+                if(changed && n->node_information.dn.state != out)
+                {
+                    n->node_information.dn.state = out;
+                    table.tables.insert(n);
+                }
+            }
+            else if(drive.need_to_operate_analog_node == nullptr)
+                drive = details::level_of(g, n, out);
+        }
+        g.last_value = g.value;
+        return drive;
+    }
+
+    // 8-bit display (logical/eight_bit_display.h): samples b7..b0 into attributes value / unknown_mask (bit set = X or Z)
+    struct EIGHT_BIT_DISPLAY
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"EIGHT_BIT_DISPLAY"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"EIGHT_BIT_DISPLAY"};
+        pin pins[8]{{{u8"b7"}}, {{u8"b6"}}, {{u8"b5"}}, {{u8"b4"}}, {{u8"b3"}}, {{u8"b2"}}, {{u8"b1"}}, {{u8"b0"}}};
+        double Ll{0.0}, Hl{5.0};
+        ::std::uint8_t value{};
+        ::std::uint8_t unknown_mask{};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<EIGHT_BIT_DISPLAY>, EIGHT_BIT_DISPLAY& g) noexcept { return {g.pins, 8}; }
+    inline bool set_attribute_define(model_reserve_type_t<EIGHT_BIT_DISPLAY>, EIGHT_BIT_DISPLAY&, ::std::size_t, variant) noexcept { return false; }
+    inline variant get_attribute_define(model_reserve_type_t<EIGHT_BIT_DISPLAY>, EIGHT_BIT_DISPLAY const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n > 1) return r;
+        r.ui8 = n == 0 ? g.value : g.unknown_mask;
+        r.type = variant_type::ui8;
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<EIGHT_BIT_DISPLAY>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"value"} : n == 1 ? ::fast_io::u8string_view{u8"unknown_mask"} : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<EIGHT_BIT_DISPLAY>, EIGHT_BIT_DISPLAY& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table&, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        ::std::uint8_t v{}, um{};
+        for(int pin = 0; pin < 8; ++pin)
+        {
+            auto* n = g.pins[pin].nodes;
+            s const st = n ? details::read_level(g, n) : s::X;
+            auto const bit = static_cast<::std::uint8_t>(1u << static_cast<unsigned>(7 - pin));
+            if(st == s::true_state) v |= bit;
+            else if(st != s::false_state)
+                um |= bit;
+        }
+        g.value = v;
+        g.unknown_mask = um;
+        return {};
+    }
+
+    // Schmitt trigger (logical/schmitt_trigger.h): an analog input moves the output only across Vth_high (up) / Vth_low (down);
+    // a digital input passes through (X / Z -> X); attributes inverted, Vth_low, Vth_high, out (read only)
+    struct SCHMITT_TRIGGER
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"SCHMITT_TRIGGER"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"SCHMITT_TRIGGER"};
+        pin pins[2]{{{u8"i"}}, {{u8"o"}}};
+        double Ll{0.0}, Hl{5.0};
+        double Vth_low{1.6666666666666666666666}, Vth_high{3.333333333333333333333};
+        bool inverted{};
+        digital_node_statement_t last_out{digital_node_statement_t::false_state};
+        digital_node_statement_t last_driven{digital_node_statement_t::X};
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<SCHMITT_TRIGGER>, SCHMITT_TRIGGER& g) noexcept { return {g.pins, 2}; }
+    inline bool set_attribute_define(model_reserve_type_t<SCHMITT_TRIGGER>, SCHMITT_TRIGGER& g, ::std::size_t n, variant vi) noexcept
+    {
+        if(n == 0 && vi.type == variant_type::boolean)
+        {
+            g.inverted = vi.boolean;
+            return true;
+        }
+        if((n == 1 || n == 2) && vi.type == variant_type::d)
+        {
+            (n == 1 ? g.Vth_low : g.Vth_high) = vi.d;
+            return true;
+        }
+        return false;
+    }
+    inline variant get_attribute_define(model_reserve_type_t<SCHMITT_TRIGGER>, SCHMITT_TRIGGER const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n == 0)
+        {
+            r.boolean = g.inverted;
+            r.type = variant_type::boolean;
+        }
+        else if(n == 1 || n == 2)
+        {
+            r.d = n == 1 ? g.Vth_low : g.Vth_high;
+            r.type = variant_type::d;
+        }
+        else if(n == 3)
+        {
+            r.digital = g.last_out;
+            r.type = variant_type::digital;
+        }
+        return r;
+    }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<SCHMITT_TRIGGER>, ::std::size_t n) noexcept
+    {
+        constexpr ::fast_io::u8string_view names[4] = {u8"inverted", u8"Vth_low", u8"Vth_high", u8"out"};
+        return n < 4 ? names[n] : ::fast_io::u8string_view{};
+    }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<SCHMITT_TRIGGER>, SCHMITT_TRIGGER& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        auto* ni = g.pins[0].nodes;
+        auto* no = g.pins[1].nodes;
+        if(!ni || !no) return {};
+        if(ni->num_of_analog_node == 0)
+        {
+            auto const st = ni->node_information.dn.state;
+            g.last_out = details::settled(st) ? st : s::indeterminate_state;
+        }
+        else
+        {
+            double const v = ni->node_information.an.voltage.real();
+            if(g.last_out == s::false_state)
+            {
+                if(v >= g.Vth_high) g.last_out = s::true_state;
+            }
+            else if(g.last_out == s::true_state)
+            {
+                if(v <= g.Vth_low) g.last_out = s::false_state;
+            }
+            else
+            {
+                if(v >= g.Vth_high) g.last_out = s::true_state;
+                else if(v <= g.Vth_low)
+                    g.last_out = s::false_state;
+            }
+        }
+        s driven = g.last_out;
+        if(g.inverted && details::settled(driven)) driven = driven == s::false_state ? s::true_state : s::false_state;
+        if(no->num_of_analog_node == 0)
+        {
+            if(no->node_information.dn.state != driven)
+            {
+                no->node_information.dn.state = driven;
+                table.tables.insert(no);
+            }
+            g.last_driven = driven;
+            return {};
+        }
+        if(g.last_driven == driven) return {};
+        g.last_driven = driven;
+        return details::level_of(g, no, driven);
+    }
+
     static_assert(defines::is_valid_digital_model<comparator> && defines::is_valid_digital_model<NOT> && defines::is_valid_digital_model<AND> &&
                   defines::is_valid_digital_model<OUTPUT> && defines::is_valid_digital_model<INPUT> && defines::is_valid_digital_model<TRI> &&
                   defines::is_valid_digital_model<FULL_ADDER> && defines::is_valid_digital_model<MUL2> && defines::is_valid_digital_model<JKFF> &&
-                  defines::is_valid_digital_model<COUNTER4>);
+                  defines::is_valid_digital_model<COUNTER4> && defines::is_valid_digital_model<DLATCH> && defines::is_valid_digital_model<DFF_ARSTN> &&
+                  defines::is_valid_digital_model<RANDOM_GENERATOR4> && defines::is_valid_digital_model<EIGHT_BIT_INPUT> &&
+                  defines::is_valid_digital_model<EIGHT_BIT_DISPLAY> && defines::is_valid_digital_model<SCHMITT_TRIGGER>);
 }  // namespace phy_engine::model

@@ -1,5 +1,7 @@
 """SURVEY.md 8f rank 4 (digital event path beyond NOT / AND): tri-state buffer, IMP / NIMP, adders, subtractors, the 2 x 2
-multiplier, D / T / T-bar / JK flip-flops and the 4-bit counter -- loader element codes 210-212, 220-229 (dll_api.h:110-124).
+multiplier, D / T / T-bar / JK flip-flops, the 4-bit counter, the 4-bit pseudo-random generator, 8-bit input / display and the
+Schmitt trigger (digital and analog input) -- loader element codes 210-212, 220-233 (dll_api.h:110-131) -- plus the D latch and
+the asynchronous-reset flip-flop of the plug-in API.
 
 tests/cpp/digital_blocks.cpp is source compatible with the reference's plug-in API; compiled against the REAL reference's headers
 (oracle/Makefile: ref_digital) it printed tests/golden/digital_blocks.json: every probe after every tick for the exhaustive
@@ -21,7 +23,7 @@ def _compare(exe):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got, ref = json.loads(out.stdout), json.load(open(GOLDEN))
-    assert sorted(got) == sorted(ref) and len(ref) == 14
+    assert sorted(got) == sorted(ref) and len(ref) == 22
     for name, r in ref.items():
         assert got[name]["in"] == r["in"], name
         bad = [t for t, (a, b) in enumerate(zip(got[name]["out"], r["out"])) if a != b]
@@ -39,11 +41,18 @@ def test_golden_covers_every_state_of_every_block():
     ref = json.load(open(GOLDEN))
     for name, r in ref.items():
         n_in = len(r["in"][0])
+        if name.startswith("SCHMITT_TRIGGER_analog") or name == "EIGHT_BIT":
+            continue
         if n_in <= 3:
             assert {tuple(v) for v in r["in"][: 4 ** n_in]} == {tuple((c // 4 ** k) % 4 for k in range(n_in)) for c in range(4 ** n_in)}, name
         assert all(0 <= s <= 3 for v in r["out"] for s in v), name
     assert max(max(v) for v in ref["TRI"]["out"]) == 3  # a disabled tri-state buffer really shows Z
     assert {tuple(v) for v in ref["COUNTER4_free"]["out"]} >= {(0, 0, 0, 1), (1, 0, 0, 0)}
+    # hysteresis: 3.0 V on the way up is still L, 2.0 V on the way down still H
+    trig = dict(zip((v[0] for v in ref["SCHMITT_TRIGGER_analog"]["in"]), ref["SCHMITT_TRIGGER_analog"]["out"]))
+    ups = [o[0] for i, o in zip(ref["SCHMITT_TRIGGER_analog"]["in"], ref["SCHMITT_TRIGGER_analog"]["out"])]
+    assert ups[3] == 0 and ups[5] == 1 and ups[7] == 1 and ups[9] == 0 and trig
+    assert any(v[9] for v in ref["EIGHT_BIT"]["out"]) and {v[8] for v in ref["EIGHT_BIT"]["out"]} != {0}
 
 
 @pytest.mark.gpu
