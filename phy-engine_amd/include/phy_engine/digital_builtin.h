@@ -1090,10 +1090,172 @@ namespace phy_engine::model
         return details::level_of(g, no, driven);
     }
 
+    // ---- four-state helpers of synthesised netlists (logical/resolve2.h, case_eq.h, is_unknown.h, tick_delay.h): these keep Z on
+    // their inputs (no Z -> X folding)
+    namespace details
+    {
+        template <typename G>
+        inline digital_node_statement_t read_raw(G const& g, node_t* n) noexcept
+        {
+            using s = digital_node_statement_t;
+            if(!n) return s::indeterminate_state;
+            if(n->num_of_analog_node == 0) return n->node_information.dn.state;
+            double const v = n->node_information.an.voltage.real();
+            return v >= g.Hl ? s::true_state : (v <= g.Ll ? s::false_state : s::indeterminate_state);
+        }
+    }  // namespace details
+    template <int KIND>  // 0 RESOLVE2 (a b o: Z yields, equal passes, else X), 1 CASE_EQ (ia ib o: a === b, never X), 2 IS_UNKNOWN (i o: X or Z -> H)
+    struct four_state_op
+    {
+        inline static constexpr ::fast_io::u8string_view names[3] = {u8"RESOLVE2", u8"CASE_EQ", u8"IS_UNKNOWN"};
+        inline static constexpr int n_pins = KIND == 2 ? 2 : 3;
+        inline static constexpr ::fast_io::u8string_view model_name{names[KIND]};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::update_table};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{names[KIND]};
+        pin pins[n_pins]{};
+        double Ll{0.0}, Hl{5.0};
+        digital_node_statement_t last_out{digital_node_statement_t::X};
+        constexpr four_state_op() noexcept
+        {
+            constexpr char8_t const* pn[3][3] = {{u8"a", u8"b", u8"o"}, {u8"ia", u8"ib", u8"o"}, {u8"i", u8"o"}};
+            for(int k = 0; k < n_pins; ++k) pins[k].name = ::fast_io::u8string_view{pn[KIND][k]};
+        }
+    };
+    using RESOLVE2 = four_state_op<0>;
+    using CASE_EQ = four_state_op<1>;
+    using IS_UNKNOWN = four_state_op<2>;
+    template <int KIND>
+    inline pin_view generate_pin_view_define(model_reserve_type_t<four_state_op<KIND>>, four_state_op<KIND>& g) noexcept
+    {
+        return {g.pins, static_cast<::std::size_t>(four_state_op<KIND>::n_pins)};
+    }
+    template <int KIND>
+        requires(KIND != 0)
+    inline bool set_attribute_define(model_reserve_type_t<four_state_op<KIND>>, four_state_op<KIND>& g, ::std::size_t n, variant vi) noexcept
+    {
+        if(vi.type != variant_type::d || n > 1) return false;
+        (n == 0 ? g.Ll : g.Hl) = vi.d;
+        return true;
+    }
+    template <int KIND>
+        requires(KIND != 0)
+    inline variant get_attribute_define(model_reserve_type_t<four_state_op<KIND>>, four_state_op<KIND> const& g, ::std::size_t n) noexcept
+    {
+        variant r{};
+        if(n > 1) return r;
+        r.d = n == 0 ? g.Ll : g.Hl;
+        r.type = variant_type::d;
+        return r;
+    }
+    template <int KIND>
+        requires(KIND != 0)
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<four_state_op<KIND>>, ::std::size_t n) noexcept
+    {
+        return n == 0 ? ::fast_io::u8string_view{u8"Ll"} : n == 1 ? ::fast_io::u8string_view{u8"Hl"} : ::fast_io::u8string_view{};
+    }
+    template <int KIND>
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<four_state_op<KIND>>, four_state_op<KIND>& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t) noexcept
+    {
+        using s = digital_node_statement_t;
+        constexpr int NP = four_state_op<KIND>::n_pins;
+        for(int k = 0; k < NP; ++k)
+            if(!g.pins[k].nodes) return {};
+        auto* no = g.pins[NP - 1].nodes;
+        auto const a = details::read_raw(g, g.pins[0].nodes);
+        s out{};
+        if constexpr(KIND == 0)
+        {
+            auto const b = details::read_raw(g, g.pins[1].nodes);
+            out = a == s::high_impedence_state ? b : (b == s::high_impedence_state ? a : (a == b ? a : s::indeterminate_state));  // resolve2.h:50-57
+        }
+        else if constexpr(KIND == 1)
+            out = a == details::read_raw(g, g.pins[1].nodes) ? s::true_state : s::false_state;  // case_eq.h:88
+        else
+            out = (a == s::indeterminate_state || a == s::high_impedence_state) ? s::true_state : s::false_state;  // is_unknown.h:96-98
+        if(no->num_of_analog_node == 0)
+        {
+            if(no->node_information.dn.state != out)
+            {
+                no->node_information.dn.state = out;
+                table.tables.insert(no);
+            }
+            g.last_out = out;
+            return {};
+        }
+        if constexpr(KIND == 0) return details::level_of(g, no, out);  // resolve2.h:70-77: drives on every call
+        else
+        {
+            if(g.last_out == out) return {};
+            g.last_out = out;
+            return details::level_of(g, no, out);
+        }
+    }
+
+    // tick delay (logical/tick_delay.h): the output is the input of `ticks` digital_clk() calls ago; advances once per tick (in the
+    // before-all phase only); the line starts filled with the first input seen; ticks = 0 passes through
+    struct TICK_DELAY
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"TICK_DELAY"};
+        inline static constexpr digital_update_method_t digital_update_method{digital_update_method_t::before_all_clk};
+        inline static constexpr model_device_type device_type{model_device_type::digital};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"TICK_DELAY"};
+        pin pins[2]{{{u8"i"}}, {{u8"o"}}};
+        double Ll{0.0}, Hl{5.0};
+        ::std::size_t ticks{1};
+        ::std::vector<digital_node_statement_t> pipe{};
+        digital_node_statement_t last_out{digital_node_statement_t::X};
+        TICK_DELAY() = default;
+        explicit TICK_DELAY(::std::size_t t) : ticks{t} {}
+    };
+    inline pin_view generate_pin_view_define(model_reserve_type_t<TICK_DELAY>, TICK_DELAY& g) noexcept { return {g.pins, 2}; }
+    inline bool set_attribute_define(model_reserve_type_t<TICK_DELAY>, TICK_DELAY&, ::std::size_t, variant) noexcept { return false; }
+    inline variant get_attribute_define(model_reserve_type_t<TICK_DELAY>, TICK_DELAY const&, ::std::size_t) noexcept { return {}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<TICK_DELAY>, ::std::size_t) noexcept { return {}; }
+    inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<TICK_DELAY>, TICK_DELAY& g,
+                                                                                       ::phy_engine::digital::digital_node_update_table& table, double,
+                                                                                       digital_update_method_t method) noexcept
+    {
+        using s = digital_node_statement_t;
+        if(method != digital_update_method_t::before_all_clk) return {};
+        auto* no = g.pins[1].nodes;
+        if(!no) return {};
+        auto const in = details::read_raw(g, g.pins[0].nodes);
+        s out = in;
+        if(g.ticks != 0)
+        {
+            if(g.pipe.size() != g.ticks)
+            {
+                g.pipe.assign(g.ticks, in);
+                g.last_out = s::indeterminate_state;
+            }
+            out = g.pipe[g.ticks - 1];
+            for(::std::size_t i = g.ticks - 1; i > 0; --i) g.pipe[i] = g.pipe[i - 1];
+            g.pipe[0] = in;
+        }
+        if(no->num_of_analog_node == 0)
+        {
+            no->node_information.dn.state = out;
+            if(g.last_out != out)
+            {
+                g.last_out = out;
+                table.tables.insert(no);
+            }
+            return {};
+        }
+        if(out == s::false_state) return {g.Ll, no};
+        if(out == s::true_state) return {g.Hl, no};
+        return {};
+    }
+
     static_assert(defines::is_valid_digital_model<comparator> && defines::is_valid_digital_model<NOT> && defines::is_valid_digital_model<AND> &&
                   defines::is_valid_digital_model<OUTPUT> && defines::is_valid_digital_model<INPUT> && defines::is_valid_digital_model<TRI> &&
                   defines::is_valid_digital_model<FULL_ADDER> && defines::is_valid_digital_model<MUL2> && defines::is_valid_digital_model<JKFF> &&
                   defines::is_valid_digital_model<COUNTER4> && defines::is_valid_digital_model<DLATCH> && defines::is_valid_digital_model<DFF_ARSTN> &&
                   defines::is_valid_digital_model<RANDOM_GENERATOR4> && defines::is_valid_digital_model<EIGHT_BIT_INPUT> &&
-                  defines::is_valid_digital_model<EIGHT_BIT_DISPLAY> && defines::is_valid_digital_model<SCHMITT_TRIGGER>);
+                  defines::is_valid_digital_model<EIGHT_BIT_DISPLAY> && defines::is_valid_digital_model<SCHMITT_TRIGGER> &&
+                  defines::is_valid_digital_model<RESOLVE2> && defines::is_valid_digital_model<CASE_EQ> && defines::is_valid_digital_model<IS_UNKNOWN> &&
+                  defines::is_valid_digital_model<TICK_DELAY>);
 }  // namespace phy_engine::model

@@ -1,0 +1,3 @@
+// path-compatible forwarding header (reference: include/phy_engine/model/models/digital/logical/resolve2.h)
+#pragma once
+#include <phy_engine/digital_builtin.h>

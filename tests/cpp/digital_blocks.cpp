@@ -28,6 +28,10 @@
 #include <phy_engine/model/models/digital/logical/eight_bit_input.h>
 #include <phy_engine/model/models/digital/logical/eight_bit_display.h>
 #include <phy_engine/model/models/digital/logical/schmitt_trigger.h>
+#include <phy_engine/model/models/digital/logical/resolve2.h>
+#include <phy_engine/model/models/digital/logical/case_eq.h>
+#include <phy_engine/model/models/digital/logical/is_unknown.h>
+#include <phy_engine/model/models/digital/logical/tick_delay.h>
 #include <phy_engine/model/models/linear/VDC.h>
 #include <phy_engine/model/models/linear/resistance.h>
 
@@ -268,6 +272,12 @@ int main()
     ok = ok && run("RANDOM_GENERATOR4", m::RANDOM_GENERATOR4{}, {4, 5}, {0, 1, 2, 3}, 300);
     ok = ok && run("RANDOM_GENERATOR4_free", m::RANDOM_GENERATOR4{}, {4}, {0, 1, 2, 3}, 80);  // reset pin left open
     ok = ok && run("SCHMITT_TRIGGER_digital", m::SCHMITT_TRIGGER{}, {0}, {1}, 30);
+    ok = ok && run("RESOLVE2", m::RESOLVE2{}, {0, 1}, {2}, 30);
+    ok = ok && run("CASE_EQ", m::CASE_EQ{}, {0, 1}, {2}, 30);
+    ok = ok && run("IS_UNKNOWN", m::IS_UNKNOWN{}, {0}, {1}, 20);
+    ok = ok && run("TICK_DELAY_0", m::TICK_DELAY{0}, {0}, {1}, 40);
+    ok = ok && run("TICK_DELAY_1", m::TICK_DELAY{1}, {0}, {1}, 40);
+    ok = ok && run("TICK_DELAY_3", m::TICK_DELAY{3}, {0}, {1}, 60);
     ok = ok && run_eight_bit();
     ok = ok && run_schmitt_analog("SCHMITT_TRIGGER_analog", false);
     ok = ok && run_schmitt_analog("SCHMITT_TRIGGER_analog_inverted", true);

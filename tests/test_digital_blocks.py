@@ -1,7 +1,8 @@
 """SURVEY.md 8f rank 4 (digital event path beyond NOT / AND): tri-state buffer, IMP / NIMP, adders, subtractors, the 2 x 2
 multiplier, D / T / T-bar / JK flip-flops, the 4-bit counter, the 4-bit pseudo-random generator, 8-bit input / display and the
-Schmitt trigger (digital and analog input) -- loader element codes 210-212, 220-233 (dll_api.h:110-131) -- plus the D latch and
-the asynchronous-reset flip-flop of the plug-in API.
+Schmitt trigger (digital and analog input) -- loader element codes 210-212, 220-233 (dll_api.h:110-131) -- plus the D latch, the
+asynchronous-reset flip-flop, RESOLVE2 / CASE_EQ / IS_UNKNOWN and the tick delay line of the plug-in API (every model under
+model/models/digital except the Verilog module).
 
 tests/cpp/digital_blocks.cpp is source compatible with the reference's plug-in API; compiled against the REAL reference's headers
 (oracle/Makefile: ref_digital) it printed tests/golden/digital_blocks.json: every probe after every tick for the exhaustive
@@ -23,7 +24,7 @@ def _compare(exe):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     got, ref = json.loads(out.stdout), json.load(open(GOLDEN))
-    assert sorted(got) == sorted(ref) and len(ref) == 22
+    assert sorted(got) == sorted(ref) and len(ref) == 28
     for name, r in ref.items():
         assert got[name]["in"] == r["in"], name
         bad = [t for t, (a, b) in enumerate(zip(got[name]["out"], r["out"])) if a != b]
