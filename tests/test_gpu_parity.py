@@ -460,3 +460,68 @@ def test_dense_circuit_single_large_front(oracle_mod, geometry, monkeypatch):
     for b in range(2):
         assert max_err(x[b], o.x, *LIN) <= 1.0
     e.close()
+
+
+# ---- circuits of >= 3000 rows other than the RC mesh through the split schedule (the default there) ----------
+def test_ac_on_large_circuit_split_schedule(oracle_mod):
+    """Small-signal AC of a 45 x 45 diode mesh: the real-equivalent system has 4 054 rows, so the AC engine runs the split
+    schedule (parts + top levels) with its iterative refinement; three frequencies around the mesh's corner against the oracle."""
+    deck = pe.deck.rc_mesh(45, 45, 1, True)
+    omegas = [2e8, 2e9, 2e10]
+    o = oracle_mod.Oracle(deck)
+    ref = o.analyze_ac(omegas)
+    assert ref is not None and all(r is not None for r in ref)
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0)
+        e.load_deck(deck)
+        e.reset()
+        e.analyze_dc(pe.ffi.MODE_OP)
+        for w, r in zip(omegas, ref):
+            x, rc = e.analyze_ac(w)
+            assert rc == 0
+            assert np.all(np.abs(x[0] - r) <= 1e-9 + 1e-6 * np.abs(r)), w
+    finally:
+        e.close()
+
+
+def test_large_rlc_line_split_schedule(oracle_mod):
+    """A 1 100-section L-C line with series loss, driven by a 1 V step through 50 ohm: 1 101 nodes + 1 100 inductor branches + the
+    source = 3 303 rows (zero diagonal entries on every branch row: static pivoting does real work), 40 transient steps, two
+    instances with different inductances, against the oracle."""
+    n = 1100
+    d = pe.deck.Deck()
+    d.n_nodes = 2 * n + 2
+    d.add("VDC", (1, 0), 1.0)
+    d.add("R", (1, 2), 50.0)
+    for k in range(n):
+        a, mid, b = 2 + 2 * k, 3 + 2 * k, 4 + 2 * k
+        d.add("L", (a, mid), 2.5e-9)
+        d.add("R", (mid, b), 0.05)
+        d.add("C", (b, 0), 1e-12)
+    d.add("R", (2 * n + 2, 0), 50.0)
+    scale = np.array([1.0, 1.3])
+    refs = []
+    for s in scale:
+        dd = pe.deck.Deck()
+        dd.n_nodes = d.n_nodes
+        for kind, pins, par in d.devices:
+            vals = list(par)
+            if kind == "L":
+                vals[0] *= s
+            dd.add(kind, pins, *vals)
+        o = oracle_mod.Oracle(dd)
+        o.analyze_tr(2e-11, 40)
+        refs.append(o.x.copy())
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0)
+        e.load_deck(d, batch=2, overrides={"L": (2.5e-9 * scale)[:, None, None] * np.ones((2, n, 1))})
+        e.reset()
+        st = e.analyze_tr(2e-11, 40)
+        x = e.solution()
+        assert e.info()["rows"] >= 3000 and e.info()["n_parts"] > 1 and st["rc"] == 0
+        for b in range(2):
+            assert max_err(x[b], refs[b], *LIN) <= 1.0
+    finally:
+        e.close()
