@@ -29,6 +29,12 @@ void phy_engine_clear_error(void);
 /* dll_api.h:143-150.  Returns NULL on failure; *vec_pos / *chunk_pos are malloc'd and released by destroy_circuit. */
 void* create_circuit(int* elements, size_t ele_size, int* wires, size_t wires_size, double* properties, size_t** vec_pos, size_t** chunk_pos,
                      size_t* comp_size);
+/* dll_api.h:156-168: create_circuit plus a string table for Verilog sources.  The string table is accepted and ignored; a netlist
+ * that contains element code 300 / 301 (Verilog module / synthesised netlist: out of scope) is refused with a
+ * message, every other netlist is built exactly as create_circuit builds it. */
+void* create_circuit_ex(int* elements, size_t ele_size, int* wires, size_t wires_size, double* properties, char const* const* texts,
+                        size_t const* text_sizes, size_t text_count, size_t const* element_src_index, size_t const* element_top_index,
+                        size_t** vec_pos, size_t** chunk_pos, size_t* comp_size);
 void destroy_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos);
 
 int circuit_set_analyze_type(void* circuit_ptr, uint32_t analyze_type_value); /* 0 OP, 1 DC, 2 AC, 3 ACOP, 4 TR, 5 TROP */

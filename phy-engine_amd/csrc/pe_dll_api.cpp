@@ -377,6 +377,21 @@ void* create_circuit(int* elements, size_t ele_size, int* wires, size_t wires_si
 }
 
 // src/dll_main.cpp:2861-2881
+// src/dll_main.cpp create_circuit_ex: the same netlist builder; Verilog elements are the only thing the string table serves
+void* create_circuit_ex(int* elements, size_t ele_size, int* wires, size_t wires_size, double* properties, char const* const*, size_t const*, size_t,
+                        size_t const*, size_t const*, size_t** vec_pos, size_t** chunk_pos, size_t* comp_size)
+{
+    if(elements)
+        for(size_t i = 0; i < ele_size; ++i)
+            if(elements[i] == 300 || elements[i] == 301)
+            {
+                phy_engine_clear_error();
+                set_err("create_circuit_ex: Verilog elements (code " + std::to_string(elements[i]) + ") are not supported by the MI355X loader");
+                return nullptr;
+            }
+    return create_circuit(elements, ele_size, wires, wires_size, properties, vec_pos, chunk_pos, comp_size);
+}
+
 void destroy_circuit(void* circuit_ptr, size_t* vec_pos, size_t* chunk_pos)
 {
     if(circuit_ptr)

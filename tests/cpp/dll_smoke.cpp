@@ -49,6 +49,20 @@ int main()
     std::size_t *vp2{}, *cp2{}, cs2{};
     if(create_circuit(bad, 2, nullptr, 0, properties, &vp2, &cp2, &cs2) != nullptr) return 8;
     if(phy_engine_last_error()[0] == 0) return 9;
+    // create_circuit_ex (dll_api.h:156-168): same netlist without Verilog elements builds; a Verilog element is refused loudly
+    {
+        char const* texts[] = {"module m; endmodule"};
+        std::size_t sizes[] = {19}, src_index[] = {0, 0, 0}, top_index[] = {0, 0, 0};
+        std::size_t *vp3{}, *cp3{}, cs3{};
+        int elems[] = {0, 4, 1};
+        double props[] = {5.0, 1000.0};
+        int w3[] = {1, 0, 2, 0, 1, 1, 0, 0, 2, 1, 0, 0};
+        void* c3 = create_circuit_ex(elems, 3, w3, 12, props, texts, sizes, 1, src_index, top_index, &vp3, &cp3, &cs3);
+        if(!c3 || cs3 != 2) return 10;
+        destroy_circuit(c3, vp3, cp3);
+        if(create_circuit_ex(bad, 2, nullptr, 0, properties, texts, sizes, 1, src_index, top_index, &vp2, &cp2, &cs2) != nullptr) return 11;
+        if(phy_engine_last_error()[0] == 0) return 12;
+    }
     destroy_circuit(cptr, vec_pos, chunk_pos);
     return 0;
 }
