@@ -116,7 +116,9 @@ namespace pe
         int keep_l21;           // 1: a later launch may reuse the factors with a separate forward pass (linear circuit, refactor_every_solve = 0)
         int wave_m, wave_p, max_m, max_p;
         int lds_slot;           // doubles of one wavefront's panel slot (largest p*(m+u) of a wave front)
-        int lds_sslot;          // doubles of one wavefront's solve scratch
+        int lds_sslot;          // doubles of one wavefront's solve scratch (+ its backward stack, lds_bstack_off doubles in)
+        int lds_bstack_off{};   // the backward pass keeps the solved vectors of a wave front's ancestors inside the subtree on a stack:
+        int const *f_wstack{}, *f_wpar{};  //   offsets of a wave front's vector and of its parent's (-1: root of the subtree)
         int lds_wave_stage{}, lds_coop_stage{};  // doubles of the staged block of a wavefront / of the workgroup in the triangular solves
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
         int lds_solve_doubles;  // ... of the triangular-solve kernels of the split schedule

@@ -186,6 +186,8 @@ namespace
         HIPCHK(h, pool.upload(V.f_rows, S.f_rows));
         HIPCHK(h, pool.upload(V.f_child_ptr, S.f_child_ptr));
         HIPCHK(h, pool.upload(V.f_child, S.f_child));
+        HIPCHK(h, pool.upload(V.f_wstack, S.f_wstack));
+        HIPCHK(h, pool.upload(V.f_wpar, S.f_wpar));
         HIPCHK(h, pool.upload(V.f_rel, S.f_rel));
         HIPCHK(h, pool.upload(V.f_inv_off, S.f_inv_off));
         HIPCHK(h, pool.upload(V.f_cnp, S.f_cnp));
@@ -217,7 +219,8 @@ namespace
         V.lds_slot = so.wave_m * (so.wave_m + 1);  // a wavefront's slot holds its fronts whole (order <= wave_m) + the right-hand-side column
         V.lds_wave_stage = so.wave_m * so.wave_p;              // a wavefront stages the whole m x p panel of its (small) fronts
         V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
-        V.lds_sslot = so.wave_m + V.lds_wave_stage + 64;       // t[m] + staged block + partial sums of one wavefront
+        V.lds_bstack_off = so.wave_m + V.lds_wave_stage + 64;  // t[m] + staged block + partial sums of one wavefront,
+        V.lds_sslot = V.lds_bstack_off + std::max(1, S.wave_stack);  // + the backward stack (the solved vectors along one path of a wave subtree)
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
             need = std::max(need, so.panel_doubles + so.panel_reserve);

@@ -1197,6 +1197,55 @@ namespace pe
         tm.sync();
     }
 
+    // Backward step of a front inside a wavefront's subtree.  A child's update rows are a subset of its parent's rows, so below the
+    // subtree's root the ancestors' unknowns come from the parent's solved vector, kept on an LDS stack (offsets fixed by the
+    // symbolic analysis) and indexed by the relative map the assembly uses (f_rel) -- not from HBM behind the parent's store.  One memory
+    // round per front (its factor panel), no drain between fronts; the root gathers from w as front_backward does.
+    template <class Team>
+    PE_DEV void front_backward_stacked(Team const& tm, DevView const& V, int b, int s_in, double* sc)
+    {
+        int const s = tm.uniform(s_in);
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        int const T = tm.size(), t0 = tm.tid();
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        double const* Lg = fac + V.f_lptr[s];
+        double const* Ug = fac + V.f_uptr[s];
+        int const par = V.f_wpar[s];
+        double* stack = sc + V.lds_bstack_off;
+        double* t = stack + V.f_wstack[s];  // [m]: this front's solved vector, read by its children
+        double* Ub = sc + V.wave_m;        // staged U11 [p x p, ld p] + U12 [p x u, ld p]
+        if(par < 0)
+        {
+            int const* rows = V.f_rows + V.f_rows_ptr[s];
+            for(int j = t0; j < u; j += T) t[p + j] = w[rows[j]];
+        }
+        else
+        {
+            int const* rel = V.f_rel + V.f_rows_ptr[s];
+            double const* tp = stack + par;
+            for(int j = t0; j < u; j += T) t[p + j] = tp[rel[j]];
+        }
+        for(int i = t0; i < p; i += T) t[i] = w[c0 + i];
+        {
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * p; idx += T)
+            {
+                int const k = fdiv(idx, rp), i = idx - k * p;
+                Ub[idx] = Lg[i + k * m];
+            }
+        }
+        stage_copy<4>(Ub + p * p, Ug, p * u, t0, T);
+        tm.sync_lds();
+        tm.for_each_wave(
+            [&](int wv, int lane, int)
+            {
+                if(wv == 0) tm.tri_upper(t, Ub, p, p, u, lane);
+            });
+        tm.sync_lds();
+        for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
+    }
+
     template <class Team>
     PE_DEV void forward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
@@ -1227,7 +1276,23 @@ namespace pe
                 auto wt = tm.wave_team(lane);
                 double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
                 int const q0 = tm.uniform(wp[wv]);
-                for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q) front_backward(wt, V, b, V.wave_list[q], sc, V.wave_m, V.lds_wave_stage);
+                for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q)
+                {
+                    int const sq = tm.uniform(V.wave_list[q]);
+                    int const pq = V.f_p[sq], mq = pq + V.f_u[sq];
+                    // (every wave front fits the staging block by construction; the general routine stays as the fallback, followed
+                    // by the gather that puts its solved vector on the stack for the children)
+                    if(mq <= 64 && mq <= V.wave_m && mq * pq <= V.lds_wave_stage) front_backward_stacked(wt, V, b, sq, sc);
+                    else
+                    {
+                        front_backward(wt, V, b, sq, sc, V.wave_m, V.lds_wave_stage);
+                        double const* wb = V.w + static_cast<long long>(b) * V.rows;
+                        double* tq = sc + V.lds_bstack_off + V.f_wstack[sq];
+                        int const* rows = V.f_rows + V.f_rows_ptr[sq];
+                        for(int i = wt.tid(); i < mq; i += wt.size()) tq[i] = i < pq ? wb[V.f_col0[sq] + i] : wb[rows[i - pq]];
+                        wt.sync_lds();
+                    }
+                }
             });
         tm.sync();
     }

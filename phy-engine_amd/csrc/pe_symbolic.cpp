@@ -846,6 +846,9 @@ namespace pe
         }
         // executors: wave w of part q -> q * (W + 1) + w ; cooperative phase of part q -> q * (W + 1) + W ; top fronts: none
         ivec exec_of(nf, -1), wroot_of(nf, -1);
+        S.f_wstack.assign(nf, 0);
+        S.f_wpar.assign(nf, -1);
+        S.wave_stack = 1;
         {
             // wave subtree roots per part, LPT over the W wavefronts
             std::vector<ivec> wroots(K);
@@ -855,6 +858,9 @@ namespace pe
                 int const P = S.f_parent[s];
                 bool const inner = P >= 0 && part_of[P] == part_of[s] && S.f_kind[P] == 0;
                 wroot_of[s] = inner ? wroot_of[P] : s;
+                S.f_wpar[s] = inner ? S.f_wstack[P] : -1;
+                S.f_wstack[s] = inner ? S.f_wstack[P] + S.f_p[P] + S.f_u[P] : 0;
+                S.wave_stack = std::max(S.wave_stack, S.f_wstack[s] + S.f_p[s] + S.f_u[s]);
                 if(!inner) wroots[part_of[s]].push_back(s);
             }
             for(int q = 0; q < K; ++q)

@@ -64,6 +64,8 @@ namespace pe
         long long work_doubles{};               // (unused)
         long long wave_panel_doubles{};         // largest p*(m+u) of a wave front (LDS doubles of one wavefront's slot)
         std::vector<int> f_kind;                // 0: wave front, 1: cooperative front of a part, 2: top front
+        std::vector<int> f_wstack, f_wpar;      // wave fronts: offset of their solved vector on the wavefront's backward stack, and their parent's (-1: subtree root)
+        int wave_stack{1};                      // doubles of the deepest stack (sum of the front orders along a path inside a wave subtree)
         int n_parts{1};
         // part q, wavefront w: wave_list[wave_ptr[q*(W+1)+w] .. wave_ptr[q*(W+1)+w+1]) in postorder (entry W of a part is empty)
         std::vector<int> wave_ptr, wave_list;
