@@ -525,3 +525,33 @@ def test_large_rlc_line_split_schedule(oracle_mod):
             assert max_err(x[b], refs[b], *LIN) <= 1.0
     finally:
         e.close()
+
+
+def test_floating_node_in_large_circuit_reports_singular_split_schedule(oracle_mod):
+    """A 60 x 60 linear mesh (3 604 rows: split schedule) plus two extra nodes joined by one resistor and nothing else: the matrix is
+    structurally fine and numerically singular ([[g, -g], [-g, g]]), the reference's factorisation fails (circuit.h:1517).  Both
+    instances must report it -- the bad-pivot flag of a front travels through the per-front check, the workgroup's flag word and
+    the host's Newton loop -- and a healthy circuit loaded afterwards on the same engine must solve."""
+    deck = pe.deck.rc_mesh(60, 60, 1, False)
+    n_extra = deck.n_nodes + 2
+    deck.n_nodes = n_extra
+    deck.add("R", (n_extra - 1, n_extra), 1000.0)
+    o = oracle_mod.Oracle(deck)
+    assert not o.analyze_dc("DC")
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0)
+        e.load_deck(deck, batch=2)
+        e.reset()
+        st = e.analyze_dc(pe.ffi.MODE_DC, check=False)
+        assert st["rc"] != 0 and e.info()["n_parts"] > 1
+        assert list(e.state()["status"]) == [pe.ffi.ERR_SINGULAR, pe.ffi.ERR_SINGULAR]
+        good = pe.deck.rc_mesh(60, 60, 1, False)
+        og = oracle_mod.Oracle(good)
+        assert og.analyze_dc("DC")
+        e.load_deck(good, batch=2)
+        e.reset()
+        e.analyze_dc(pe.ffi.MODE_DC)
+        assert max_err(e.solution()[1], og.x, *LIN) <= 1.0
+    finally:
+        e.close()
