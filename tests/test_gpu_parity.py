@@ -555,3 +555,20 @@ def test_floating_node_in_large_circuit_reports_singular_split_schedule(oracle_m
         assert max_err(e.solution()[1], og.x, *LIN) <= 1.0
     finally:
         e.close()
+
+
+def test_failing_transient_rolls_back_in_split_schedule(monkeypatch):
+    """test_bridge_gmin0_fails_like_reference through the split schedule (forced on the small circuit): the host Newton loop of
+    run_m2_tr must stop at the same kind of failure, keep the results before it and roll the time back (circuit.h:249-253)."""
+    monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", "1")
+    e = pe.ffi.Engine(device=0)
+    try:
+        meta, gx, deck = golden("bridge_gmin0_fail")
+        snaps, trace, fail = run_engine_case(e, meta, deck)
+        assert max_err(snaps[:1, 0, :], gx[:1], *NL) <= 1.0
+        assert 76 <= fail <= 82
+        st = e.state()
+        assert st["status"][0] in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_NO_CONVERGENCE)
+        assert abs(st["t"][0] - (fail - 1) * meta["dt"]) < 1e-12
+    finally:
+        e.close()
