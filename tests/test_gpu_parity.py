@@ -572,3 +572,21 @@ def test_failing_transient_rolls_back_in_split_schedule(monkeypatch):
         assert abs(st["t"][0] - (fail - 1) * meta["dt"]) < 1e-12
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("name,tol", [("generators_tr", LIN), ("generators_trop", LIN), ("iac_rc_trop", LIN), ("coupled_l_k09_tr", LIN), ("coupled_l_k09_trop", LIN),
+                                      ("controlled_mix_tr", NL), ("cmos_inverter_tr", NL), ("bjt_amp_tr", NL), ("relay_ramp_tr", NL), ("center_tap_ratio", NL),
+                                      ("nmos_triode_op", NL)])
+def test_stampers_through_split_schedule(name, tol, monkeypatch):
+    """The per-phase kernels of the split schedule (k_m2_eval / k_m2_companion: time-dependent sources, coupled inductors, relay
+    state, three-pin devices) on the stamper goldens, forced on these small circuits: same results and Newton trajectory."""
+    monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", "1")
+    e = pe.ffi.Engine(device=0)
+    try:
+        meta, gx, deck = golden(name)
+        snaps, trace, fail = run_engine_case(e, meta, deck)
+        assert fail == -1 and len(snaps) == len(gx)
+        assert max_err(snaps[:, 0, :], gx, *tol) <= 1.0
+        assert list(trace) == meta["newton_iters"]
+    finally:
+        e.close()
