@@ -590,3 +590,34 @@ def test_stampers_through_split_schedule(name, tol, monkeypatch):
         assert list(trace) == meta["newton_iters"]
     finally:
         e.close()
+
+
+def test_checkpoint_and_ac_in_split_schedule(monkeypatch):
+    """Checkpoint -> new engine -> restore continues bit-identically, and the AC goldens, with the split schedule forced on."""
+    monkeypatch.setenv("PHY_ENGINE_HIP_SPLIT", "1")
+    deck, r, c = pe.deck.rc_mesh_params(32, 32, [1, 2, 3], True)
+    ov = {"R": r[:, :, None], "C": c[:, :, None]}
+    e1 = pe.ffi.Engine(device=0)
+    e2 = pe.ffi.Engine(device=0)
+    try:
+        e1.set_options(g_min=0.0)
+        e1.load_deck(deck, batch=3, overrides=ov)
+        e1.reset()
+        e1.analyze_tr(1e-10, 40)
+        want = e1.solution().copy()
+        e1.reset()
+        e1.analyze_tr(1e-10, 15)
+        blob = e1.checkpoint()
+        e2.set_options(g_min=0.0)
+        e2.load_deck(deck, batch=3, overrides=ov)
+        e2.restore(blob)
+        e2.analyze_tr(1e-10, 25)
+        assert np.array_equal(e2.solution(), want)
+        for name in ("ac_rlc_diode_acop", "ac_linear_mix"):
+            meta, gx, d = golden(name)
+            xs = run_ac_case(e1, meta, d)
+            g = golden_complex(meta, gx)
+            assert np.all(np.abs(xs - g) <= 1e-9 + 1e-6 * np.abs(g)), name
+    finally:
+        e1.close()
+        e2.close()
