@@ -457,6 +457,25 @@ namespace pe
         }
     }
 
+    // the same with 16 wavefronts per workgroup: few instances leave the GPU idle, a top front then gets a whole CU's wavefront slots
+    __global__ void __launch_bounds__(1024) k_m2_factor_top_wide(DevView V, int level, int nlev)
+    {
+        // one workgroup per front of `level`; nlev > 1: a run of single-front levels (a chain at the top of the tree) handled by
+        // the same workgroup one after the other -- saves a launch per level where a launch is most of the level's time
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        for(int l = level; l < level + nlev; ++l)
+        {
+            int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
+            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            {
+                if(tm.tid() == 0) atomicOr(V.flags + b, 4);
+                return;
+            }
+        }
+    }
+
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)
     {
         int const b = static_cast<int>(blockIdx.y);
@@ -544,6 +563,12 @@ namespace pe
     }
 
     // one Newton iteration of every active instance in the split schedule: stamp -> LU -> solves -> Newton bits.
+    static int getenv_int(char const* name, int def)
+    {
+        char const* v = std::getenv(name);
+        return v && *v ? std::atoi(v) : def;
+    }
+
     // workgroups per instance of the elementwise kernels (eval, stamp, winit, finish, companion): ~2048 rows each for large
     // batches; few instances spread over more workgroups (these kernels are gathers: latency-bound at low occupancy)
     static int grid_per_instance(DevView const& V)
@@ -563,6 +588,7 @@ namespace pe
         {
             hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top<MINW>), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_wide), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts<MINW>), lds_s);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_s);
             if(e != hipSuccess) return e;
@@ -593,7 +619,13 @@ namespace pe
             if(ev0) (void)hipEventRecord(ev0, st);
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
-            for(int l = 0; l < V.n_top_levels; l += run(l)) hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
+            bool const wide = MINW == 2 && getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;  // one workgroup per CU anyway (LDS plan); (developer knob for A/B runs)
+            for(int l = 0; l < V.n_top_levels; l += run(l))
+            {
+                if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), lds, st, V, l, run(l));
+                else
+                    hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
+            }
         }
         else
         {
