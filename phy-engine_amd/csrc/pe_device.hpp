@@ -101,6 +101,12 @@ namespace pe
         int const* f_cnp;            // per child edge: leading update rows of the child that are pivot rows of the parent
         int const* f_inv;
         int const *f_asm_ptr, *asm_slot, *asm_pos;
+        // destination-centric assembly lists (pe_symbolic.hpp: build_assembly_lists) and the LDS layout of every front
+        int const* f_mode;             // 0 whole front, 1 pivot panels, 2 chain link
+        int const *gl_ptr, *gl_rptr;   // [nfronts + 1] into gl_dst / gl_cnt
+        long long const* gl_sptr;      // [nfronts + 1] into gl_src
+        unsigned short const* gl_dst;
+        int const *gl_cnt, *gl_src;
         double* zero;  // one 0.0 in device memory: where the masked-out lanes of an unconditional gather point
         long long const *f_lptr, *f_uptr, *f_sptr;
         int const *row_src, *col_src;

@@ -176,7 +176,7 @@ namespace
         return v && *v ? std::max(1, std::atoi(v)) : batch;
     }
 
-    int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic const& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
+    int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
     {
         V.nfronts = S.nfronts;
         HIPCHK(h, pool.upload(V.f_col0, S.f_col0));
@@ -234,6 +234,15 @@ namespace
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
+        // the LDS caps are fixed now: layout of every front + the assembly lists that go with it
+        if(!pe::build_assembly_lists(S, V.lds_slot, V.lds_doubles - 2)) return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
+        HIPCHK(h, pool.upload(V.f_mode, S.f_mode));
+        HIPCHK(h, pool.upload(V.gl_ptr, S.gl_ptr));
+        HIPCHK(h, pool.upload(V.gl_rptr, S.gl_rptr));
+        HIPCHK(h, pool.upload(V.gl_sptr, S.gl_sptr));
+        HIPCHK(h, pool.upload(V.gl_dst, S.gl_dst));
+        HIPCHK(h, pool.upload(V.gl_cnt, S.gl_cnt));
+        HIPCHK(h, pool.upload(V.gl_src, S.gl_src));
         HIPCHK(h, pool.alloc(V.zero, 1));
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));

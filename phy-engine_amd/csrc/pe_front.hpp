@@ -505,8 +505,9 @@ namespace pe
         // column g[m] of the front -- pivot part from w, update part from the children's update vectors -- so that after the
         // block loop g[0..p) is the forward-substituted solution of these pivots and g[p..m) this front's update vector.
         // Saves the separate forward pass over the factor panels whenever a factorisation is followed by a solve.
-        bool const full = m * (m + 1) <= cap;
-        bool const chain = !full && ch1 - ch0 == 1 && V.f_u[V.f_child[ch0]] == m;  // then f_rel of the child is the identity
+        int const mode = tm.uniform(V.f_mode[s]);  // fixed with the launch geometry (build_assembly_lists): same rule, one place
+        bool const full = mode == 0;
+        bool const chain = mode == 2;  // the single child's update matrix IS this front: f_rel of the child is the identity
         int const ldu = full ? m : p;
         int const nlds = full ? m * m : m * p + p * u;
         double* Lp = lds;
@@ -539,149 +540,106 @@ namespace pe
         if(e0 < e1) place(pos0, v0);
         for(int e = e0 + T; e < e1; e += T) place(V.asm_pos[e], a[V.asm_slot ? V.asm_slot[e] : e]);
         long long const cka = tm.clock();
-        // the first children's metadata (wavefront-uniform: scalar loads) is requested before the fence, off the path between
-        // the fence and the first loads from the children's update matrices
-        constexpr int PC = 4;
-        int pc_u[PC], pc_rows[PC];
-        long long pc_s[PC];
-#pragma unroll
-        for(int q = 0; q < PC; ++q)
-        {
-            int c = s;  // (no such child: this front's own entries, never used)
-            if(ch0 + q < ch1) c = V.f_child[ch0 + q];
-            pc_u[q] = V.f_u[c];
-            pc_s[q] = V.f_sptr[c];
-            pc_rows[q] = V.f_rows_ptr[c];
-        }
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
         if(ch1 > ch0) tm.sync();
         else
             tm.sync_lds();
-        for(int ch = ch0; ch < ch1; ++ch)
+        if(chain)
         {
-            int uc, rows0;
-            long long sp;
+            // the child's update matrix IS this front (a long separator split into links): straight copies
+            int const c = V.f_child[ch0];
+            double const* Sc = arena + V.f_sptr[c];
+            for(int base = t0; base < m * p; base += 4 * T)
             {
-                int const k = ch - ch0;
-                if(k < PC)
-                {
-                    uc = pc_u[0], sp = pc_s[0], rows0 = pc_rows[0];
+                double v[4];
 #pragma unroll
-                    for(int q = 1; q < PC; ++q)
-                        if(k == q) uc = pc_u[q], sp = pc_s[q], rows0 = pc_rows[q];
-                }
-                else
-                {
-                    int const c = V.f_child[ch];
-                    uc = V.f_u[c], sp = V.f_sptr[c], rows0 = V.f_rows_ptr[c];
-                }
+                for(int q = 0; q < 4; ++q) v[q] = Sc[base + q * T < m * p ? base + q * T : 0];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                    if(base + q * T < m * p) Lp[base + q * T] += v[q];
             }
-            double const* Sc = arena + sp;
-            int const* rel = V.f_rel + rows0;
-            float const rcp = 1.0f / static_cast<float>(uc);
-            int const n = uc * uc;
-            if(chain)
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int base = t0; base < p * u; base += 4 * T)
             {
-                // the child's update matrix IS this front (a long separator split into links): straight copies
-                for(int base = t0; base < m * p; base += 4 * T)
+                double v[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
                 {
-                    double v[4];
-#pragma unroll
-                    for(int q = 0; q < 4; ++q) v[q] = Sc[base + q * T < m * p ? base + q * T : 0];
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                        if(base + q * T < m * p) Lp[base + q * T] += v[q];
+                    int const idx = base + q * T;
+                    int const ix = idx < p * u ? idx : 0;
+                    int const cc = fdiv(ix, rp), r = ix - cc * p;
+                    v[q] = Sc[r + (p + cc) * m];
                 }
-                float const rp = 1.0f / static_cast<float>(p);
-                for(int base = t0; base < p * u; base += 4 * T)
-                {
-                    double v[4];
 #pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        int const idx = base + q * T;
-                        int const ix = idx < p * u ? idx : 0;
-                        int const cc = fdiv(ix, rp), r = ix - cc * p;
-                        v[q] = Sc[r + (p + cc) * m];
-                    }
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                        if(base + q * T < p * u) Up[base + q * T] += v[q];
-                }
-            }
-            else if(full)
-            {
-                for(int base = t0; base < n; base += 4 * T)
-                {
-                    double v[4];
-                    int d[4];
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        int const idx = base + q * T;
-                        bool const in = idx < n;
-                        int const ix = in ? idx : 0;
-                        v[q] = Sc[ix];
-                        int const j = fdiv(ix, rcp), i = ix - j * uc;
-                        d[q] = in ? rel[i] + rel[j] * m : -1;
-                    }
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                        if(d[q] >= 0) lds[d[q]] += v[q];
-                }
-            }
-            else
-            {
-                // entries of the child's update matrix that land in this front's pivot columns (its first np columns: f_rel
-                // ascends, pivots come first) and pivot rows (first np rows of the other columns); nothing else is touched
-                int const np = V.f_cnp[ch];
-                int const nA = uc * np;                       // contiguous: columns 0 .. np-1
-                for(int base = t0; base < nA; base += 4 * T)
-                {
-                    double v[4];
-                    int d[4];
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                    {
-                        int const idx = base + q * T;
-                        bool const in = idx < nA;
-                        int const ix = in ? idx : 0;
-                        v[q] = Sc[ix];
-                        int const j = fdiv(ix, rcp), i = ix - j * uc;
-                        d[q] = in ? rel[i] + rel[j] * m : -1;
-                    }
-#pragma unroll
-                    for(int q = 0; q < 4; ++q)
-                        if(d[q] >= 0) lds[d[q]] += v[q];
-                }
-                if(np > 0)
-                {
-                    int const nB = np * (uc - np);            // rows 0 .. np-1 of columns np .. uc-1
-                    float const rnp = 1.0f / static_cast<float>(np);
-                    for(int base = t0; base < nB; base += 4 * T)
-                    {
-                        double v[4];
-                        int d[4];
-#pragma unroll
-                        for(int q = 0; q < 4; ++q)
-                        {
-                            int const idx = base + q * T;
-                            bool const in = idx < nB;
-                            int const ix = in ? idx : 0;
-                            int const jj = fdiv(ix, rnp), i = ix - jj * np, j = jj + np;
-                            v[q] = Sc[i + j * uc];
-                            d[q] = in ? m * p + rel[i] + (rel[j] - p) * p : -1;
-                        }
-#pragma unroll
-                        for(int q = 0; q < 4; ++q)
-                            if(d[q] >= 0) lds[d[q]] += v[q];
-                    }
-                }
+                for(int q = 0; q < 4; ++q)
+                    if(base + q * T < p * u) Up[base + q * T] += v[q];
             }
             if(fuse)
             {
-                double const* vc = Sc + n;  // the child's update vector sits behind its update matrix
-                for(int i = t0; i < uc; i += T) g[rel[i]] += vc[i];
+                double const* vc = Sc + m * m;  // the child's update vector sits behind its update matrix
+                for(int i = t0; i < m; i += T) g[i] += vc[i];
+            }
+            tm.sync_lds();
+        }
+        else if(ch1 > ch0)
+        {
+            // Destination-centric assembly (pe_symbolic.hpp: build_assembly_lists): every LDS cell that receives anything from a
+            // child is owned by ONE thread, which adds its sources in the children's order -- no barrier between children, and
+            // the loads of all children (indices from the shared lists, values from this instance's arena) are in flight together.
+            int const n0 = V.gl_ptr[s + 1] - V.gl_ptr[s];
+            int const r_lo = V.gl_rptr[s], R = V.gl_rptr[s + 1] - r_lo;
+            unsigned short const* dst = V.gl_dst + V.gl_ptr[s];
+            int const* s0 = V.gl_src + V.gl_sptr[s];
+            int const n1 = R > 1 ? V.gl_cnt[r_lo + 1] : 0, n2 = R > 2 ? V.gl_cnt[r_lo + 2] : 0, n3 = R > 3 ? V.gl_cnt[r_lo + 3] : 0;
+            int const *s1 = s0 + n0, *s2 = s1 + n1, *s3 = s2 + n2;
+            constexpr int UN = 2;
+            for(int base = t0; base < n0; base += UN * T)
+            {
+                int d[UN];
+                double sv0[UN], sv1[UN], sv2[UN], sv3[UN];
+#pragma unroll
+                for(int q = 0; q < UN; ++q)
+                {
+                    int const c = base + q * T;
+                    bool const in = c < n0;
+                    int const cc = in ? c : 0;
+                    d[q] = in ? static_cast<int>(dst[cc]) : -1;
+                    sv0[q] = arena[s0[cc]];
+                    sv1[q] = sv2[q] = sv3[q] = 0.0;
+                    // (later rounds cover a prefix of the cells: a lane past the prefix re-reads the round's first source and drops it)
+                    if(n1 > 0) sv1[q] = arena[s1[c < n1 ? c : 0]];
+                    if(n2 > 0) sv2[q] = arena[s2[c < n2 ? c : 0]];
+                    if(n3 > 0) sv3[q] = arena[s3[c < n3 ? c : 0]];
+                }
+#pragma unroll
+                for(int q = 0; q < UN; ++q)
+                {
+                    int const c = base + q * T;
+                    if(d[q] >= 0 && (fuse || d[q] < nlds))
+                    {
+                        double acc = lds[d[q]] + sv0[q];
+                        if(c < n1) acc += sv1[q];
+                        if(c < n2) acc += sv2[q];
+                        if(c < n3) acc += sv3[q];
+                        lds[d[q]] = acc;
+                    }
+                }
+            }
+            if(R > 4)
+            {
+                // cells with more than four sources (fronts that absorbed many children): the same thread that owns the cell in
+                // the sweep above adds the remaining rounds one by one -- still no barrier (a thread re-reads its own LDS writes)
+                int const* sr = s3 + n3;
+                for(int r = 4; r < R; ++r)
+                {
+                    int const nr = V.gl_cnt[r_lo + r];
+                    for(int c = t0; c < nr; c += T)
+                    {
+                        int const dd = dst[c];
+                        if(fuse || dd < nlds) lds[dd] += arena[sr[c]];
+                    }
+                    sr += nr;
+                }
             }
             tm.sync_lds();
         }
@@ -709,71 +667,8 @@ namespace pe
                         if(w == 0) bad |= tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
                     });
                 tm.sync_lds();
-                // (a1) rows below the block (L) and columns right of it (U): one thread each; the 8 x 8 block and the
-                // thread's own row / column sit in registers, so the dependent chain is pure ALU
-                {
-                    int const nrows = m - k0 - kb;            // rows k0+kb .. m-1 of the L panel
-                    int const ncolL = p - k0 - kb;            // columns k0+kb .. p-1 of the L panel (rows k0..k0+kb)
-                    int const ncols = ncolL + u;              // plus every column of the U panel
-                    int const ngc = fuse ? 1 : 0;             // plus the right-hand-side column
-                    auto const B8 = tm.blk_load(Lp + k0 + k0 * m, m, kb, t0 & 63);  // the factored block, one entry per lane
-                    for(int q = t0; q < nrows + ncols + ngc; q += T)
-                    {
-                        double x[NB];
-                        if(q < nrows)
-                        {
-                            // x * U11 = a  (row of L): needs the upper triangle of the block
-                            double* row = Lp + (k0 + kb + q) + k0 * m;
-    #pragma unroll
-                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? row[kk * m] : 0.0;
-    #pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
-                            {
-                                if(kk < kb)
-                                {
-                                    double ucol[NB];
-    #pragma unroll
-                                    for(int r = 0; r < NB; ++r) ucol[r] = r <= kk ? tm.blk_at(B8, r, kk) : 0.0;
-                                    double const rdiag = tm.rcp(ucol[kk]);  // independent of the chain below: overlaps with it
-                                    double acc = x[kk];
-    #pragma unroll
-                                    for(int r = 0; r < NB; ++r)
-                                        if(r < kk) acc -= x[r] * ucol[r];
-                                    x[kk] = acc * rdiag;
-                                }
-                            }
-    #pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
-                                if(kk < kb) row[kk * m] = x[kk];
-                        }
-                        else
-                        {
-                            // L11 * y = a  (column of U): needs the strict lower triangle (unit diagonal)
-                            int const jc = q - nrows;
-                            double* col = jc < ncolL ? Lp + (k0 + kb + jc) * m + k0 : (jc < ncols ? Up + (jc - ncolL) * ldu + k0 : g + k0);
-    #pragma unroll
-                            for(int kk = 0; kk < NB; ++kk) x[kk] = kk < kb ? col[kk] : 0.0;
-    #pragma unroll
-                            for(int kk = 1; kk < NB; ++kk)
-                            {
-                                if(kk < kb)
-                                {
-                                    double lrow[NB];
-    #pragma unroll
-                                    for(int r = 0; r < NB; ++r) lrow[r] = r < kk ? tm.blk_at(B8, kk, r) : 0.0;
-                                    double acc = x[kk];
-    #pragma unroll
-                                    for(int r = 0; r < NB; ++r)
-                                        if(r < kk) acc -= lrow[r] * x[r];
-                                    x[kk] = acc;
-                                }
-                            }
-    #pragma unroll
-                            for(int kk = 0; kk < NB; ++kk)
-                                if(kk < kb) col[kk] = x[kk];
-                        }
-                    }
-                }
+                // (a1) rows below the block (L) and columns right of it (U): one thread each (tm.panel_solve)
+                tm.panel_solve(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, t0, T);
             }
             tm.sync_lds();
             // (b) trailing update of both panels, one 16 x 16 tile per wavefront at a time

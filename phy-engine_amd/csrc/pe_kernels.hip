@@ -57,12 +57,19 @@ namespace pe
         // LU (no pivoting) of a kb x kb block (kb <= 8) held one entry per lane: lane l <-> (row l&7, col l>>3).
         // The dependent chain runs on cross-lane shuffles, not on LDS round trips.  On return the block in memory
         // holds U on and above the diagonal and the SCALED multipliers below it.  Returns 1 on a bad pivot.
+        // (the pivots' reciprocals go to rdiag()[0..8): the row solves of panel_solve multiply by them instead of recomputing)
+        __device__ __forceinline__ double* rdiag() const
+        {
+            __shared__ double rd[8];
+            return rd;
+        }
         __device__ __forceinline__ int diag_lu8(double* blk, int ld, int kb, int lane) const
         {
             int const r = lane & 7, c = lane >> 3;
             bool const in = r < kb && c < kb;
             double v = in ? blk[r + c * ld] : (r == c ? 1.0 : 0.0);
             int bad = 0;
+            double* rd = rdiag();
 #pragma unroll
             for(int kk = 0; kk < 8; ++kk)
             {
@@ -70,12 +77,87 @@ namespace pe
                 double const lrk = __shfl(v, r + 8 * kk);
                 double const ukc = __shfl(v, kk + 8 * c);
                 if(kk < kb && (piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))) bad = 1;
-                double const l = lrk * rcp(piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
+                double const rp = rcp(piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
+                rd[kk] = rp;                 // (every lane stores the same value)
+                double const l = lrk * rp;
                 if(r > kk && c > kk) v -= l * ukc;
                 if(r > kk && c == kk) v = l;
             }
             if(in) blk[r + c * ld] = v;
             return bad;
+        }
+        // Rows below a factored KB x KB diagonal block (x U11 = a) and columns right of it (L11 y = a), one thread each, the
+        // block read through v_readlane from one entry per lane.  The split between rows and columns falls on a wavefront
+        // boundary (a wavefront solves rows OR columns: no divergent double pass); KB is a compile-time constant.
+        template <int KB>
+        __device__ __forceinline__ void panel_solve_t(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int t0, int T) const
+        {
+            int const lane = t0 & 63, wv = __builtin_amdgcn_readfirstlane(t0 >> 6), nwv = T >> 6;
+            int const nrows = m - k0 - KB, ncolL = p - k0 - KB, ncols = ncolL + u + (fuse ? 1 : 0);
+            Blk8 const B8 = blk_load(Lp + k0 + k0 * m, m, KB, lane);
+            int const row_items = (nrows + 63) >> 6, col_items = (ncols + 63) >> 6;
+            double const* rd = rdiag();
+            for(int item = wv; item < row_items + col_items; item += nwv)
+            {
+                double x[KB];
+                if(item < row_items)
+                {
+                    int const i = item * 64 + lane;
+                    bool const own = i < nrows;
+                    double* row = Lp + (k0 + KB + (own ? i : nrows - 1)) + k0 * m;
+#pragma unroll
+                    for(int kk = 0; kk < KB; ++kk) x[kk] = row[kk * m];
+#pragma unroll
+                    for(int kk = 0; kk < KB; ++kk)
+                    {
+                        double acc = x[kk];
+#pragma unroll
+                        for(int r = 0; r < kk; ++r) acc = __builtin_fma(-x[r], blk_at(B8, r, kk), acc);
+                        x[kk] = acc * rd[kk];
+                    }
+                    if(own)
+                    {
+#pragma unroll
+                        for(int kk = 0; kk < KB; ++kk) row[kk * m] = x[kk];
+                    }
+                }
+                else
+                {
+                    int const jj = (item - row_items) * 64 + lane;
+                    bool const own = jj < ncols;
+                    int const j = own ? jj : ncols - 1;
+                    double* col = j < ncolL ? Lp + (k0 + KB + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+#pragma unroll
+                    for(int kk = 0; kk < KB; ++kk) x[kk] = col[kk];
+#pragma unroll
+                    for(int kk = 1; kk < KB; ++kk)
+                    {
+                        double acc = x[kk];
+#pragma unroll
+                        for(int r = 0; r < kk; ++r) acc = __builtin_fma(-blk_at(B8, kk, r), x[r], acc);
+                        x[kk] = acc;
+                    }
+                    if(own)
+                    {
+#pragma unroll
+                        for(int kk = 1; kk < KB; ++kk) col[kk] = x[kk];
+                    }
+                }
+            }
+        }
+        __device__ __forceinline__ void panel_solve(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int t0, int T) const
+        {
+            switch(kb)
+            {
+                case 8: return panel_solve_t<8>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 7: return panel_solve_t<7>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 6: return panel_solve_t<6>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 5: return panel_solve_t<5>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 4: return panel_solve_t<4>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 3: return panel_solve_t<3>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 2: return panel_solve_t<2>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                default: return panel_solve_t<1>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+            }
         }
 
         // broadcast lane k's value (k wavefront-uniform): v_readlane, no LDS round trip
@@ -97,69 +179,81 @@ namespace pe
             return Blk8{(r < kb && c < kb) ? blk[r + c * ld] : (r == c ? 1.0 : 0.0)};
         }
         __device__ __forceinline__ double blk_at(Blk8 const& b, int r, int c) const { return bcast(b.e, r + 8 * c); }
-        // One block step (kb <= 8 pivots from k0) of a front that ONE wavefront owns (m <= 64).
+        // One block step (KB <= 8 pivots from k0) of a front that ONE wavefront owns (m <= 64).
         // Rows: lane i holds row k0 + i of the block's columns in registers and the pivot row of step kk comes from lane kk by
         // v_readlane -- the LU of the diagonal block and the solve of the rows below it (x U11 = a) are the same elimination,
         // with no LDS round trip on the dependent chain.  Columns: lane j holds the block rows of one column right of the
         // block (rest of the L panel, the U panel, the right-hand-side column) and solves L11 y = a with the multipliers read
         // from the row lanes' registers.  Same operation order as diag_lu8 + the per-thread solves of front_factor.
-        __device__ __forceinline__ int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse,
-                                                  int lane) const
+        // KB is a compile-time constant (block_step dispatches on the wavefront-uniform kb): the pivot / column loops unroll into
+        // straight-line code with no branch per entry; lanes outside the front work on a clamped row / column (valid
+        // addresses, results dropped) and rows not below the pivot take a zero multiplier instead of an exec mask.
+        template <int KB>
+        __device__ __forceinline__ int block_step_t(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int lane) const
         {
-            bool const own = lane < m - k0;
-            double* row = Lp + (k0 + lane) + k0 * m;
-            double v[8];
+            int const nrow = m - k0;  // >= KB >= 1
+            bool const own = lane < nrow;
+            double* row = Lp + (k0 + (own ? lane : nrow - 1)) + k0 * m;
+            double v[KB];
 #pragma unroll
-            for(int c = 0; c < 8; ++c) v[c] = (own && c < kb) ? row[c * m] : 0.0;
+            for(int c = 0; c < KB; ++c) v[c] = row[c * m];
             int bad = 0;
 #pragma unroll
-            for(int kk = 0; kk < 8; ++kk)
+            for(int kk = 0; kk < KB; ++kk)
             {
-                if(kk < kb)
-                {
-                    double const piv = bcast(v[kk], kk);
-                    if(piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308)) bad = 1;
-                    double const l = v[kk] * rcp(piv);
-                    bool const below = lane > kk;
+                double const piv = bcast(v[kk], kk);
+                if(piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308)) bad = 1;
+                double const l = v[kk] * rcp(piv);
+                bool const below = lane > kk;
+                double const lm = below ? l : 0.0;
 #pragma unroll
-                    for(int c = kk + 1; c < 8; ++c)
-                        if(c < kb)
-                        {
-                            double const uc = bcast(v[c], kk);
-                            if(below) v[c] -= l * uc;
-                        }
-                    if(below) v[kk] = l;
-                }
+                for(int c = kk + 1; c < KB; ++c) v[c] = __builtin_fma(-lm, bcast(v[c], kk), v[c]);
+                v[kk] = below ? l : v[kk];
             }
             if(own)
             {
 #pragma unroll
-                for(int c = 0; c < 8; ++c)
-                    if(c < kb) row[c * m] = v[c];
+                for(int c = 0; c < KB; ++c) row[c * m] = v[c];
             }
-            int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
-            bool const ownc = lane < ncols;
-            double* col = lane < ncolL ? Lp + (k0 + kb + lane) * m + k0 : (lane < ncolL + u ? Up + (lane - ncolL) * ldu + k0 : g + k0);
-            double x[8];
+            int const ncolL = p - k0 - KB, ncols = ncolL + u + (fuse ? 1 : 0);
+            if(ncols > 0)
+            {
+                bool const ownc = lane < ncols;
+                int const j = ownc ? lane : ncols - 1;
+                double* col = j < ncolL ? Lp + (k0 + KB + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                double x[KB];
 #pragma unroll
-            for(int kk = 0; kk < 8; ++kk) x[kk] = (ownc && kk < kb) ? col[kk] : 0.0;
+                for(int kk = 0; kk < KB; ++kk) x[kk] = col[kk];
 #pragma unroll
-            for(int kk = 1; kk < 8; ++kk)
-                if(kk < kb)
+                for(int kk = 1; kk < KB; ++kk)
                 {
                     double acc = x[kk];
 #pragma unroll
-                    for(int r = 0; r < 8; ++r)
-                        if(r < kk) acc -= bcast(v[r], kk) * x[r];
+                    for(int r = 0; r < kk; ++r) acc = __builtin_fma(-bcast(v[r], kk), x[r], acc);
                     x[kk] = acc;
                 }
-            if(ownc)
-            {
+                if(ownc)
+                {
 #pragma unroll
-                for(int kk = 0; kk < 8; ++kk)
-                    if(kk < kb) col[kk] = x[kk];
+                    for(int kk = 1; kk < KB; ++kk) col[kk] = x[kk];
+                }
             }
             return bad;
+        }
+        __device__ __forceinline__ int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse,
+                                                  int lane) const
+        {
+            switch(kb)
+            {
+                case 8: return block_step_t<8>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 7: return block_step_t<7>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 6: return block_step_t<6>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 5: return block_step_t<5>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 4: return block_step_t<4>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 3: return block_step_t<3>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 2: return block_step_t<2>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                default: return block_step_t<1>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+            }
         }
         // Triangular solves of the triangular-solve phase, p <= 64, one wavefront: lane i owns t[i]; the dependent chain
         // runs on lane broadcasts, the matrix columns (LDS, independent of the chain) are fetched four steps ahead.
@@ -243,38 +337,87 @@ namespace pe
         };
         __device__ __forceinline__ Acc tile_zero() const { return Acc{v4d{0.0, 0.0, 0.0, 0.0}}; }
         __device__ __forceinline__ void tile_add(Acc& a, Acc const& b) const { a.v += b.v; }
+        // Tile loads are UNCONDITIONAL: a lane outside the mr x nc part of an edge tile reads the nearest entry inside it (a
+        // valid address of the same block) instead of branching around the load, so the four loads of a tile issue back to
+        // back.  Such a lane's accumulator entries are never stored (tile_store masks them) and never reach an in-range
+        // entry: C is updated element by element, and tile_mulsub zeroes only what would (the k tail).
         __device__ __forceinline__ Acc tile_load(double const* C, int ldc, int mr, int nc, int lane) const
         {
             Acc a;
-            int const row = lane & 15, cb = lane >> 4;
+            int row = lane & 15;
+            int const cb = lane >> 4;
+            row = row < mr ? row : mr - 1;
+            double const* p = C + row;
 #pragma unroll
             for(int r = 0; r < 4; ++r)
             {
-                int const col = cb + 4 * r;
-                a.v[r] = (row < mr && col < nc) ? C[row + col * ldc] : 0.0;
+                int col = cb + 4 * r;
+                col = col < nc ? col : nc - 1;
+                a.v[r] = p[col * ldc];
             }
             return a;
         }
         __device__ __forceinline__ void tile_store(Acc const& a, double* C, int ldc, int mr, int nc, int lane) const
         {
             int const row = lane & 15, cb = lane >> 4;
-#pragma unroll
-            for(int r = 0; r < 4; ++r)
+            double* p = C + row + cb * ldc;
+            if(mr == 16 && nc == 16)  // (wavefront-uniform) interior tile: four plain stores
             {
-                int const col = cb + 4 * r;
-                if(row < mr && col < nc) C[row + col * ldc] = a.v[r];
+#pragma unroll
+                for(int r = 0; r < 4; ++r) p[4 * r * ldc] = a.v[r];
+            }
+            else if(row < mr)
+            {
+#pragma unroll
+                for(int r = 0; r < 4; ++r)
+                    if(cb + 4 * r < nc) p[4 * r * ldc] = a.v[r];
             }
         }
-        // acc -= A(mr x kd, ld lda) * B(kd x nc, ld ldb)
+        // acc -= A(mr x kd, ld lda) * B(kd x nc, ld ldb).  The operands of up to four k-steps are requested before the
+        // first MFMA (unconditional loads from clamped rows / columns); only the k tail (kd % 4) is masked.
         __device__ __forceinline__ void tile_mulsub(Acc& a, double const* A, int lda, double const* B, int ldb, int mr, int nc, int kd, int lane) const
         {
             int const ij = lane & 15, kq = lane >> 4;
-            for(int kk = 0; kk < kd; kk += 4)
+            double const* pa = A + (ij < mr ? ij : mr - 1) + kq * lda;
+            double const* pb = B + kq + (ij < nc ? ij : nc - 1) * ldb;
+            int kk = 0;
+            for(; kk + 16 <= kd; kk += 16)
             {
-                int const k = kk + kq;
-                double const av = (k < kd && ij < mr) ? -A[ij + k * lda] : 0.0;
-                double const bv = (k < kd && ij < nc) ? B[k + ij * ldb] : 0.0;
-                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, a.v, 0, 0, 0);
+                double av[4], bv[4];
+#pragma unroll
+                for(int q = 0; q < 4; ++q)
+                {
+                    av[q] = pa[(kk + 4 * q) * lda];
+                    bv[q] = pb[kk + 4 * q];
+                }
+#pragma unroll
+                for(int q = 0; q < 4; ++q) a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], -av[q], a.v, 0, 0, 0);
+            }
+            if(kk + 8 <= kd)
+            {
+                double av[2], bv[2];
+#pragma unroll
+                for(int q = 0; q < 2; ++q)
+                {
+                    av[q] = pa[(kk + 4 * q) * lda];
+                    bv[q] = pb[kk + 4 * q];
+                }
+#pragma unroll
+                for(int q = 0; q < 2; ++q) a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[q], -av[q], a.v, 0, 0, 0);
+                kk += 8;
+            }
+            if(kk + 4 <= kd)
+            {
+                double const av = pa[kk * lda], bv = pb[kk];
+                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, -av, a.v, 0, 0, 0);
+                kk += 4;
+            }
+            if(kk < kd)
+            {
+                bool const in = kk + kq < kd;
+                int const kc = in ? kq : 0;  // (a masked lane re-reads k = kk)
+                double const a0 = A[(ij < mr ? ij : mr - 1) + (kk + kc) * lda], b0 = B[kk + kc + (ij < nc ? ij : nc - 1) * ldb];
+                a.v = __builtin_amdgcn_mfma_f64_16x16x4f64(in ? b0 : 0.0, in ? -a0 : 0.0, a.v, 0, 0, 0);
             }
         }
         template <class F>

@@ -1011,4 +1011,109 @@ namespace pe
         }
         return true;
     }
+
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team)
+    {
+        int const nf = S.nfronts;
+        S.f_mode.assign(nf, 0);
+        S.gl_ptr.assign(nf + 1, 0);
+        S.gl_rptr.assign(nf + 1, 0);
+        S.gl_sptr.assign(nf + 1, 0);
+        S.gl_dst.clear();
+        S.gl_cnt.clear();
+        S.gl_src.clear();
+        if(S.arena_doubles >= (1ll << 31))
+        {
+            S.error = "update-matrix arena exceeds 2^31 doubles per instance";
+            return false;
+        }
+        std::vector<int> first, next, srcv, cells, cnt;  // per LDS cell: chained list of sources (append order = children's order)
+        std::vector<int> last;
+        for(int s = 0; s < nf; ++s)
+        {
+            long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
+            long long const cap = S.f_kind[s] == 0 ? cap_wave : cap_team;
+            int const ch0 = S.f_child_ptr[s], ch1 = S.f_child_ptr[s + 1];
+            bool const full = m * (m + 1) <= cap;
+            bool const chain = !full && ch1 - ch0 == 1 && S.f_u[S.f_child[ch0]] == m;
+            S.f_mode[s] = full ? 0 : (chain ? 2 : 1);
+            if(!chain && ch1 > ch0)
+            {
+                long long const nlds = full ? m * m : m * p + p * u;
+                if(nlds + m > 65535)
+                {
+                    S.error = "front image exceeds the 16-bit cell index of the assembly lists";
+                    return false;
+                }
+                first.assign(static_cast<size_t>(nlds + m), -1);
+                last.assign(static_cast<size_t>(nlds + m), -1);
+                next.clear();
+                srcv.clear();
+                auto add = [&](long long d, long long src)
+                {
+                    int const e = static_cast<int>(srcv.size());
+                    srcv.push_back(static_cast<int>(src));
+                    next.push_back(-1);
+                    if(first[d] < 0) first[d] = e;
+                    else
+                        next[last[d]] = e;
+                    last[d] = e;
+                };
+                for(int a = ch0; a < ch1; ++a)
+                {
+                    int const c = S.f_child[a];
+                    long long const uc = S.f_u[c], sp = S.f_sptr[c];
+                    int const* rel = S.f_rel.data() + S.f_rows_ptr[c];
+                    if(full)
+                    {
+                        for(long long j = 0; j < uc; ++j)
+                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * m, sp + i + j * uc);
+                    }
+                    else
+                    {
+                        long long np = 0;  // the child's leading update rows that are pivots of this front (f_rel ascends)
+                        while(np < uc && rel[np] < p) ++np;
+                        for(long long j = 0; j < np; ++j)
+                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * m, sp + i + j * uc);            // L panel (columns < p)
+                        for(long long j = np; j < uc; ++j)
+                            for(long long i = 0; i < np; ++i) add(m * p + rel[i] + (rel[j] - p) * p, sp + i + j * uc);  // U panel (rows < p)
+                    }
+                    for(long long i = 0; i < uc; ++i) add(nlds + rel[i], sp + uc * uc + i);  // update vector -> right-hand-side column
+                }
+                cells.clear();
+                cnt.assign(first.size(), 0);
+                for(size_t d = 0; d < first.size(); ++d)
+                    if(first[d] >= 0)
+                    {
+                        cells.push_back(static_cast<int>(d));
+                        for(int e = first[d]; e >= 0; e = next[e]) ++cnt[d];
+                    }
+                std::sort(cells.begin(), cells.end(),
+                          [&](int a, int b)
+                          {
+                              if(cnt[a] != cnt[b]) return cnt[a] > cnt[b];
+                              return srcv[first[a]] < srcv[first[b]];
+                          });
+                int const rounds = cells.empty() ? 0 : cnt[cells[0]];
+                for(int d: cells) S.gl_dst.push_back(static_cast<unsigned short>(d));
+                std::vector<int> cur(cells.size());
+                for(size_t k = 0; k < cells.size(); ++k) cur[k] = first[cells[k]];
+                for(int r = 0; r < rounds; ++r)
+                {
+                    int n_r = 0;
+                    for(size_t k = 0; k < cells.size() && cnt[cells[k]] > r; ++k)
+                    {
+                        S.gl_src.push_back(srcv[cur[k]]);
+                        cur[k] = next[cur[k]];
+                        ++n_r;
+                    }
+                    S.gl_cnt.push_back(n_r);
+                }
+            }
+            S.gl_ptr[s + 1] = static_cast<int>(S.gl_dst.size());
+            S.gl_rptr[s + 1] = static_cast<int>(S.gl_cnt.size());
+            S.gl_sptr[s + 1] = static_cast<long long>(S.gl_src.size());
+        }
+        return true;
+    }
 }  // namespace pe

@@ -79,6 +79,20 @@ namespace pe
         int max_m{};                            // largest front order
         int max_u{};
 
+        // Destination-centric assembly lists (build_assembly_lists, after the launch geometry fixed the LDS caps).  For a
+        // front s in whole-front or panel layout every LDS cell that receives a contribution from a child's update matrix
+        // (or update vector: the right-hand-side column behind the panels) is ONE cell of the list:
+        //   gl_dst[gl_ptr[s] + c]                      its offset in the front's LDS image,
+        //   gl_src[gl_sptr[s] + (n_0 + .. + n_{r-1}) + c]  the arena offset of its r-th source (children in list order), c < n_r,
+        //   n_r = gl_cnt[gl_rptr[s] + r]               cells with more than r sources (cells are sorted by source count, descending,
+        //                                              then by the address of the first source: coalesced loads of the first child).
+        // One sweep without barriers assembles all children; the summation order of a cell is the children's order.
+        std::vector<int> f_mode;                // 0 whole front in LDS, 1 pivot panels in LDS + pulled Schur tiles, 2 chain link
+        std::vector<int> gl_ptr, gl_rptr;       // [nfronts + 1]
+        std::vector<long long> gl_sptr;         // [nfronts + 1]
+        std::vector<unsigned short> gl_dst;
+        std::vector<int> gl_cnt, gl_src;
+
         // statistics
         long long nnz_LU{};      // structural nnz(L)+nnz(U) (diagonal counted once) of the supernodal pattern WITHOUT relaxation zeros
         long long nnz_LU_stored{};  // with relaxation zeros (what the dense panels hold)
@@ -91,4 +105,8 @@ namespace pe
 
     // rp/ci: CSR pattern with sorted columns; vals may be null (then every entry weighs 1).
     bool analyze(int n, int const* rp, int const* ci, double const* vals, SymbolicOptions const& opt, Symbolic& out);
+
+    // cap_wave / cap_team: LDS doubles of a wavefront's slot / of the whole workgroup (the `cap` front_factor is called with).
+    // Returns false (S.error set) when an offset does not fit its index type.
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team);
 }  // namespace pe

@@ -59,6 +59,28 @@ namespace pe
             }
             return 0;
         }
+        // rows below / columns right of a factored kb x kb diagonal block (serial stand-in of the per-thread solves)
+        void panel_solve(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int, int) const
+        {
+            double const* blk = Lp + k0 + k0 * m;
+            for(int i = k0 + kb; i < m; ++i)
+            {
+                double* row = Lp + i + k0 * m;
+                for(int kk = 0; kk < kb; ++kk)
+                {
+                    double acc = row[kk * m];
+                    for(int r = 0; r < kk; ++r) acc -= row[r * m] * blk[r + kk * m];
+                    row[kk * m] = acc * (1.0 / blk[kk + kk * m]);
+                }
+            }
+            int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
+            for(int j = 0; j < ncols; ++j)
+            {
+                double* col = j < ncolL ? Lp + (k0 + kb + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                for(int kk = 1; kk < kb; ++kk)
+                    for(int r = 0; r < kk; ++r) col[kk] -= blk[kk + r * m] * col[r];
+            }
+        }
         int diag_lu8(double* blk, int ld, int kb, int) const
         {
             for(int kk = 0; kk < kb; ++kk)
