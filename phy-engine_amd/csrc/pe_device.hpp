@@ -100,6 +100,7 @@ namespace pe
         long long const* f_inv_off;  // per child edge (index into f_child), cooperative parents only
         int const* f_cnp;            // per child edge: leading update rows of the child that are pivot rows of the parent
         int const* f_inv;
+        unsigned const* f_bmask;     // per child edge: 16-row blocks of the parent's update rows the child touches (bit min(t, 31))
         int const *f_asm_ptr, *asm_slot, *asm_pos;
         // destination-centric assembly lists (pe_symbolic.hpp: build_assembly_lists) and the LDS layout of every front
         int const* f_mode;             // 0 whole front, 1 pivot panels, 2 chain link

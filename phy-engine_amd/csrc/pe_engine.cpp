@@ -192,6 +192,7 @@ namespace
         HIPCHK(h, pool.upload(V.f_inv_off, S.f_inv_off));
         HIPCHK(h, pool.upload(V.f_cnp, S.f_cnp));
         HIPCHK(h, pool.upload(V.f_inv, S.f_inv));
+        HIPCHK(h, pool.upload(V.f_bmask, S.f_bmask));
         HIPCHK(h, pool.upload(V.f_asm_ptr, S.f_asm_ptr));
         HIPCHK(h, pool.upload(V.asm_slot, S.asm_slot));
         HIPCHK(h, pool.upload(V.asm_pos, S.asm_pos));

@@ -23,6 +23,12 @@
 #else
     #define PE_DEV inline
 #endif
+// developer aid: -DPE_ASM_MARKS puts named comments into the device assembly (scripts/asm_regions.py counts instructions per region)
+#if defined(PE_ASM_MARKS) && defined(__HIPCC__)
+    #define PE_MARK(name) asm volatile("; PE_MARK " name ::: "memory")
+#else
+    #define PE_MARK(name) ((void)0)
+#endif
 
 namespace pe
 {
@@ -517,12 +523,14 @@ namespace pe
         int const c0 = V.f_col0[s];
         double* w = V.w + static_cast<long long>(b) * V.rows;
         long long const ck0 = tm.clock();
+        PE_MARK("prologue");
         // the entries of A owned by this front and its slice of the right-hand side: their loads depend on nothing a previous
         // front wrote -- requested first, they fly behind the zeroing of the front (and that front's stores still in flight)
         int const e0 = V.f_asm_ptr[s] + t0, e1 = V.f_asm_ptr[s + 1];
         int const pos0 = e0 < e1 ? V.asm_pos[e0] : 0;
         double const v0 = e0 < e1 ? a[V.asm_slot ? V.asm_slot[e0] : e0] : 0.0;
         double const w0 = (fuse && t0 < p) ? w[c0 + t0] : 0.0;
+        PE_MARK("zero");
         for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
         if(fuse)
         {
@@ -530,6 +538,7 @@ namespace pe
             for(int i = t0 + T; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
         }
         tm.sync_lds();
+        PE_MARK("place");
         auto place = [&](int pos, double v)
         {
             int const r = pos >> 16, c = pos & 0xffff;
@@ -540,6 +549,7 @@ namespace pe
         if(e0 < e1) place(pos0, v0);
         for(int e = e0 + T; e < e1; e += T) place(V.asm_pos[e], a[V.asm_slot ? V.asm_slot[e] : e]);
         long long const cka = tm.clock();
+        PE_MARK("children");
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
         if(ch1 > ch0) tm.sync();
         else
@@ -589,61 +599,59 @@ namespace pe
             int const n0 = V.gl_ptr[s + 1] - V.gl_ptr[s];
             int const r_lo = V.gl_rptr[s], R = V.gl_rptr[s + 1] - r_lo;
             unsigned short const* dst = V.gl_dst + V.gl_ptr[s];
-            int const* s0 = V.gl_src + V.gl_sptr[s];
-            int const n1 = R > 1 ? V.gl_cnt[r_lo + 1] : 0, n2 = R > 2 ? V.gl_cnt[r_lo + 2] : 0, n3 = R > 3 ? V.gl_cnt[r_lo + 3] : 0;
-            int const *s1 = s0 + n0, *s2 = s1 + n1, *s3 = s2 + n2;
-            constexpr int UN = 2;
-            for(int base = t0; base < n0; base += UN * T)
+            int const* sr = V.gl_src + V.gl_sptr[s];
+            // Rounds are taken two at a time (round r covers the first n_r cells; n_r falls quickly: most cells have one or two
+            // sources).  Per sweep a thread keeps UN cells in flight and requests the indices of its NEXT batch before it waits
+            // for the values of the current one, so a batch costs one memory latency, not two.
+            constexpr int UN = 4;
+            for(int r = 0; r < R; r += 2)
             {
-                int d[UN];
-                double sv0[UN], sv1[UN], sv2[UN], sv3[UN];
+                int const na = V.gl_cnt[r_lo + r], nb = r + 1 < R ? V.gl_cnt[r_lo + r + 1] : 0;
+                int const *sa = sr, *sb = sr + na;
+                sr = sb + nb;
+                int d[UN], ia[UN], ib[UN];
+                auto fetch_idx = [&](int base)
+                {
 #pragma unroll
-                for(int q = 0; q < UN; ++q)
+                    for(int q = 0; q < UN; ++q)
+                    {
+                        int const c = base + q * T;
+                        int const cc = c < na ? c : 0;
+                        d[q] = dst[cc];
+                        ia[q] = sa[cc];
+                        ib[q] = nb > 0 ? sb[c < nb ? c : 0] : 0;  // (a lane past the round's prefix re-reads its first source and drops it)
+                    }
+                };
+                if(t0 < na) fetch_idx(t0);
+                for(int base = t0; base < na; base += UN * T)
                 {
-                    int const c = base + q * T;
-                    bool const in = c < n0;
-                    int const cc = in ? c : 0;
-                    d[q] = in ? static_cast<int>(dst[cc]) : -1;
-                    sv0[q] = arena[s0[cc]];
-                    sv1[q] = sv2[q] = sv3[q] = 0.0;
-                    // (later rounds cover a prefix of the cells: a lane past the prefix re-reads the round's first source and drops it)
-                    if(n1 > 0) sv1[q] = arena[s1[c < n1 ? c : 0]];
-                    if(n2 > 0) sv2[q] = arena[s2[c < n2 ? c : 0]];
-                    if(n3 > 0) sv3[q] = arena[s3[c < n3 ? c : 0]];
-                }
+                    double va[UN], vb[UN];
+                    int dd[UN];
 #pragma unroll
-                for(int q = 0; q < UN; ++q)
-                {
-                    int const c = base + q * T;
-                    if(d[q] >= 0 && (fuse || d[q] < nlds))
+                    for(int q = 0; q < UN; ++q)
                     {
-                        double acc = lds[d[q]] + sv0[q];
-                        if(c < n1) acc += sv1[q];
-                        if(c < n2) acc += sv2[q];
-                        if(c < n3) acc += sv3[q];
-                        lds[d[q]] = acc;
+                        va[q] = arena[ia[q]];
+                        vb[q] = arena[ib[q]];
+                        dd[q] = d[q];
                     }
-                }
-            }
-            if(R > 4)
-            {
-                // cells with more than four sources (fronts that absorbed many children): the same thread that owns the cell in
-                // the sweep above adds the remaining rounds one by one -- still no barrier (a thread re-reads its own LDS writes)
-                int const* sr = s3 + n3;
-                for(int r = 4; r < R; ++r)
-                {
-                    int const nr = V.gl_cnt[r_lo + r];
-                    for(int c = t0; c < nr; c += T)
+                    if(base + UN * T < na) fetch_idx(base + UN * T);
+#pragma unroll
+                    for(int q = 0; q < UN; ++q)
                     {
-                        int const dd = dst[c];
-                        if(fuse || dd < nlds) lds[dd] += arena[sr[c]];
+                        int const c = base + q * T;
+                        if(c < na && (fuse || dd[q] < nlds))
+                        {
+                            double acc = lds[dd[q]] + va[q];
+                            if(c < nb) acc += vb[q];
+                            lds[dd[q]] = acc;
+                        }
                     }
-                    sr += nr;
                 }
             }
             tm.sync_lds();
         }
         long long const ck1 = tm.clock();
+        PE_MARK("blockloop");
         int const NW = tm.n_waves();
         constexpr int NB = 8;
         // A bad pivot is reported once per front, after the block loop: nothing below branches on or indexes by matrix values,
@@ -729,6 +737,7 @@ namespace pe
         }
         if(tm.sync_or(bad)) return false;
         long long const ck2 = tm.clock();
+        PE_MARK("schur");
         if(profile == 1 && V.prof && t0 == 0)
         {
             V.prof[b * PE_PROF + 6] += ck1 - ck0;
@@ -745,8 +754,9 @@ namespace pe
             int const ng = fuse ? m + (m & 1) : 0;                      // the right-hand-side column sits right behind the panels
             long long* csp = reinterpret_cast<long long*>(lds + nlds + ng);  // per child: arena offset of its update matrix,
             int* cuc = reinterpret_cast<int*>(csp + nch);               //            its order,
-            int* linv = cuc + nch + (nch & 1);                          //            its inverse map (rows p.. of this front)
-            bool const staged = !full && !chain && (static_cast<long long>(nch) * (u + 3) + 2) * 4 <= static_cast<long long>(cap - nlds - ng) * 8;
+            unsigned* cmk = reinterpret_cast<unsigned*>(cuc + nch);     //            the 16-row blocks of this front's update rows it touches,
+            int* linv = cuc + 2 * nch;                                  //            its inverse map (rows p.. of this front)
+            bool const staged = !full && !chain && nch <= 64 && (static_cast<long long>(nch) * (u + 4) + 2) * 4 <= static_cast<long long>(cap - nlds - ng) * 8;
             if(staged)
             {
                 for(int q = t0; q < nch; q += T)
@@ -754,6 +764,7 @@ namespace pe
                     int const cc = V.f_child[ch0 + q];
                     csp[q] = V.f_sptr[cc];
                     cuc[q] = V.f_u[cc];
+                    cmk[q] = V.f_bmask[ch0 + q];
                 }
                 float const ru = 1.0f / static_cast<float>(u);
                 for(int idx = t0; idx < nch * u; idx += T)
@@ -814,15 +825,24 @@ namespace pe
                                                     });
                                     return raw;
                                 };
+                                // only the children that touch this tile's row block AND column block are pulled (a front that
+                                // absorbed many children sees two or three of them per tile): one ballot over the staged block masks
+                                auto todo = tm.tile_children(cmk, nch, ti, tj, lane);
+                                auto pop = [&]()
+                                {
+                                    int const q = __builtin_ctzll(todo);
+                                    todo &= todo - 1;
+                                    return q;
+                                };
                                 auto raw0 = tm.tile_zero(), raw1 = tm.tile_zero();
-                                if(nch > 0) raw0 = pull(0);
-                                if(nch > 1) raw1 = pull(1);
+                                if(todo) raw0 = pull(pop());
+                                if(todo) raw1 = pull(pop());
                                 tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
                                 tm.tile_add(acc, raw0);
                                 tm.tile_add(acc, raw1);
-                                for(int q = 2; q < nch; ++q)
+                                while(todo)
                                 {
-                                    auto const rq = pull(q);
+                                    auto const rq = pull(pop());
                                     tm.tile_add(acc, rq);
                                 }
                                 tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
@@ -854,6 +874,7 @@ namespace pe
                 });
         }
         long long const ck3 = tm.clock();
+        PE_MARK("stores");
         if(fuse)
         {
             for(int i = t0; i < p; i += T) w[c0 + i] = g[i];
@@ -888,6 +909,7 @@ namespace pe
         else
             for(int i = t0 + (need_l21 ? 0 : m * p); i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
         tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
+        PE_MARK("end");
         if(profile && V.prof && t0 == 0)
         {
             long long* q = V.prof + b * PE_PROF + (profile == 2 ? 32 : 8 + 6 * (full ? 0 : (chain ? 2 : 1)));

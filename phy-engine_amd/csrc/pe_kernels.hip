@@ -324,6 +324,13 @@ namespace pe
             if(own) t[lane] = ti;
         }
 
+        // children (<= 64, one per lane) whose staged block mask has both the tile's row block and its column block: bit q set
+        __device__ __forceinline__ unsigned long long tile_children(unsigned const* cmk, int nch, int ti, int tj, int lane) const
+        {
+            unsigned const mk = lane < nch ? cmk[lane] : 0u;
+            int const bi = ti < 31 ? ti : 31, bj = tj < 31 ? tj : 31;
+            return __ballot((((mk >> bi) & (mk >> bj)) & 1u) != 0u);
+        }
         // ---- 16 x 16 fp64 tiles on the matrix core: v_mfma_f64_16x16x4_f64.
         // The instruction takes A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] from lane l and keeps
         // D[(l>>4) + 4r][l&15] in accumulator register r (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").

@@ -991,6 +991,7 @@ namespace pe
         // inverse relative maps of every parent front
         S.f_inv_off.assign(S.f_child.size(), -1);
         S.f_cnp.assign(S.f_child.size(), 0);
+        S.f_bmask.assign(S.f_child.size(), 0u);
         S.f_inv.clear();
         S.wave_panel_doubles = 1;
         for(int s = 0; s < nf; ++s)
@@ -1003,7 +1004,12 @@ namespace pe
                 S.f_inv_off[a] = static_cast<long long>(S.f_inv.size());
                 S.f_inv.resize(S.f_inv.size() + m, -1);
                 int* inv = S.f_inv.data() + S.f_inv_off[a];
-                for(int i = 0; i < S.f_u[c]; ++i) inv[S.f_rel[S.f_rows_ptr[c] + i]] = i;
+                for(int i = 0; i < S.f_u[c]; ++i)
+                {
+                    int const l = S.f_rel[S.f_rows_ptr[c] + i];
+                    inv[l] = i;
+                    if(l >= S.f_p[s]) S.f_bmask[a] |= 1u << std::min((l - S.f_p[s]) >> 4, 31);
+                }
                 int np = 0;
                 while(np < S.f_u[c] && S.f_rel[S.f_rows_ptr[c] + np] < S.f_p[s]) ++np;
                 S.f_cnp[a] = np;

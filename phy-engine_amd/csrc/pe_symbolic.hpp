@@ -76,6 +76,7 @@ namespace pe
         std::vector<long long> f_inv_off;
         std::vector<int> f_cnp;                 // per child edge: how many of the child's update rows are pivots of the parent (a prefix: f_rel ascends)
         std::vector<int> f_inv;
+        std::vector<unsigned> f_bmask;          // per child edge: bit min(t, 31) set when the child has an update row among the parent's update rows 16 t .. 16 t + 15
         int max_m{};                            // largest front order
         int max_u{};
 

@@ -112,6 +112,14 @@ namespace pe
                 for(int i = 0; i < k; ++i) t[i] -= Ub[i + k * ld] * t[k];
             }
         }
+        unsigned long long tile_children(unsigned const* cmk, int nch, int ti, int tj, int) const
+        {
+            unsigned long long todo = 0;
+            int const bi = ti < 31 ? ti : 31, bj = tj < 31 ? tj : 31;
+            for(int q = 0; q < nch; ++q)
+                if(((cmk[q] >> bi) & (cmk[q] >> bj)) & 1u) todo |= 1ull << q;
+            return todo;
+        }
         // plain-loop stand-in for the 16 x 16 matrix-core tiles
         struct Acc
         {
