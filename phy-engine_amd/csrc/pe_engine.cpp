@@ -122,13 +122,20 @@ struct pe_hip_engine
     } csr;
 };
 
+// a failed HIP call is NOT "no device" unless the runtime says so: out-of-memory at a large batch, a launch failure or a
+// memcpy error are internal errors of a machine that has a GPU (callers and tests tell them apart)
+static inline int hip_error_code(hipError_t e)
+{
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorInsufficientDriver) ? PE_HIP_ERR_NO_DEVICE : PE_HIP_ERR_INTERNAL;
+}
+
 #define HIPCHK(h, expr)                                                                             \
     do {                                                                                            \
         hipError_t e__ = (expr);                                                                    \
         if(e__ != hipSuccess)                                                                       \
         {                                                                                           \
             (h)->err = std::string("HIP error: ") + hipGetErrorString(e__) + " at " #expr;          \
-            return PE_HIP_ERR_NO_DEVICE;                                                            \
+            return hip_error_code(e__);                                                             \
         }                                                                                           \
     } while(0)
 
@@ -164,7 +171,7 @@ namespace
         V.i_abstol = o.i_abstol > 0.0 ? o.i_abstol : 1e-12;
         V.i_reltol = o.i_reltol > 0.0 ? o.i_reltol : V.v_reltol;
         V.max_newton = o.max_newton > 0 ? o.max_newton : 64;
-        V.keep_l21 = o.refactor_every_solve ? 0 : 1;  // (only a linear circuit actually reuses; a non-linear one refactors anyway)
+        V.keep_l21 = (o.refactor_every_solve || V.nonlinear) ? 0 : 1;  // only a linear circuit reuses its factors (separate forward pass over L21)
         V.r_open = r_open_of(h);
     }
 
@@ -326,6 +333,27 @@ namespace
         return so;
     }
 
+    // Symbolic analysis + the LDS-fit escalation every caller needs (resident circuit AND the solve_csr_real seam): a front's
+    // right-hand-side column (m doubles) must fit the reserve behind its panels, and the top of the tree the launch table.
+    // (1) a larger reserve; (2) the whole LDS of a CU for one workgroup; else give up loudly.  `geometry_rows`: row count the
+    // launch geometry is chosen by (0: the resident single-workgroup kernel, as the solver seam runs).
+    int analyze_fitting(pe_hip_engine* h, int batch, int geometry_rows, int n, int const* rp, int const* ci, double const* vals, pe::Symbolic& S,
+                        pe::SymbolicOptions& so)
+    {
+        so = symbolic_options(h, batch, geometry_rows);
+        for(int attempt = 0;; ++attempt)
+        {
+            if(!pe::analyze(n, rp, ci, vals, so, S))
+                return fail(h, S.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
+            bool const too_deep = static_cast<int>(S.top_ptr.size()) - 1 > 64;
+            bool const fits = S.max_m + 8 <= so.panel_reserve;
+            if(fits && !too_deep) return PE_HIP_OK;
+            if(attempt == 2) return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: a front of order " + std::to_string(S.max_m) + " does not fit the LDS of a CU");
+            so = symbolic_options(h, batch, geometry_rows, std::max(384, S.max_m + 72), attempt == 1 ? 1 : 0);
+            if(too_deep) so.n_parts = 1;
+        }
+    }
+
     int ensure_symbolic(pe_hip_engine* h, bool tr, double dt)
     {
         int const cls = tr ? 1 : 0;
@@ -335,26 +363,14 @@ namespace
         if(!h->sym_values_override.empty()) av = h->sym_values_override;
         else
             pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
-        pe::SymbolicOptions so = symbolic_options(h, h->hc.batch, h->hc.rows);
-        for(int attempt = 0;; ++attempt)
+        pe::SymbolicOptions so{};
         {
-            if(!pe::analyze(h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), so, h->sym))
+            int const rc = analyze_fitting(h, h->hc.batch, h->hc.rows, h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), h->sym, so);
+            if(rc != PE_HIP_OK)
             {
                 h->sym_class = -1;
-                return fail(h, h->sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + h->sym.error);
+                return rc;
             }
-            // A front's right-hand-side column (m doubles) must fit the reserve behind its panels, and the top of the tree the
-            // launch table.  Escalation: (1) a larger reserve; (2) the whole LDS of a CU for one workgroup; else give up loudly.
-            bool const too_deep = static_cast<int>(h->sym.top_ptr.size()) - 1 > 64;
-            bool const fits = h->sym.max_m + 8 <= so.panel_reserve;
-            if(fits && !too_deep) break;
-            if(attempt == 2)
-            {
-                h->sym_class = -1;
-                return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: a front of order " + std::to_string(h->sym.max_m) + " does not fit the LDS of a CU");
-            }
-            so = symbolic_options(h, h->hc.batch, h->hc.rows, std::max(384, h->sym.max_m + 72), attempt == 1 ? 1 : 0);
-            if(too_deep) so.n_parts = 1;
         }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
         {
@@ -969,6 +985,9 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     if(h->hc.rows == 0 || nsteps == 0) return PE_HIP_OK;
     int rc = ensure_symbolic(h, true, dt);
     if(rc != PE_HIP_OK) return rc;
+    // A failed solve is not sticky (circuit.h:242-254: the reference rolls tr_duration back, returns false, and the next
+    // analyze() simply tries again from that state -- e.g. after the caller raised g_min): every run starts with all instances live.
+    HIPCHK(h, hipMemsetAsync(h->V.status, 0, static_cast<size_t>(h->hc.batch) * sizeof(int), h->stream));
     std::vector<long long> s0, i0;
     rc = snapshot_counters(h, s0, i0);
     if(rc != PE_HIP_OK) return rc;
@@ -1024,6 +1043,7 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     if(h->hc.rows == 0) return PE_HIP_OK;
     int rc = ensure_symbolic(h, false, 0.0);
     if(rc != PE_HIP_OK) return rc;
+    HIPCHK(h, hipMemsetAsync(h->V.status, 0, static_cast<size_t>(h->hc.batch) * sizeof(int), h->stream));  // no sticky failure (see analyze_tr)
     std::vector<long long> s0, i0;
     rc = snapshot_counters(h, s0, i0);
     if(rc != PE_HIP_OK) return rc;
@@ -1253,9 +1273,8 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
         auto const t0 = clk::now();
         C.have = false;
         C.pool.release();
-        pe::SymbolicOptions const so = symbolic_options(h, 1, 0);
-        if(!pe::analyze(n, row_ptr, col_ind, values, so, C.sym))
-            return fail(h, C.sym.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "solve_csr_real: " + C.sym.error);
+        pe::SymbolicOptions so{};
+        if(int const rc = analyze_fitting(h, 1, 0, n, row_ptr, col_ind, values, C.sym, so); rc != PE_HIP_OK) return rc;
         pe::DevView V{};
         V.rows = n;
         V.n_nodes = n;

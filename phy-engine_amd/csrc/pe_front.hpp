@@ -16,6 +16,7 @@
 #pragma once
 #include "pe_device.hpp"
 
+#include <cassert>
 #include <cmath>
 
 #if defined(__HIPCC__)
@@ -516,6 +517,9 @@ namespace pe
         bool const chain = mode == 2;  // the single child's update matrix IS this front: f_rel of the child is the identity
         int const ldu = full ? m : p;
         int const nlds = full ? m * m : m * p + p * u;
+#if !defined(__HIPCC__)
+        assert(nlds + (fuse ? m : 0) <= cap && "front image + right-hand-side column overrun the team's LDS region");
+#endif
         double* Lp = lds;
         double* Up = lds + m * p;
         double* g = lds + nlds;  // [m] right-hand-side column (fuse)

@@ -9,7 +9,7 @@
 #include <cstring>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInsufficientDriver = 35, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101 };
 typedef struct emu_stream* hipStream_t;
 struct emu_event { std::chrono::steady_clock::time_point t; };
 typedef emu_event* hipEvent_t;
@@ -23,6 +23,7 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t b) { std::memset(p, v, b); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t b, hipStream_t) { std::memset(p, v, b); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t b, hipMemcpyKind) { std::memcpy(d, s, b); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t b, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, b); return hipSuccess; }
 inline hipError_t hipMemcpy2D(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind)

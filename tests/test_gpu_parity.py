@@ -138,6 +138,38 @@ def test_bridge_gmin0_fails_like_reference(eng):
     assert abs(st["t"][0] - (fail - 1) * meta["dt"]) < 1e-12   # tr_duration rolled back (circuit.h:249-253)
 
 
+def test_failed_solve_is_not_sticky(eng, oracle_mod):
+    """circuit.h:242-254: after a failed transient the next analyze() tries again from the rolled-back state.  The g_min = 0
+    bridge fails; with g_min raised to 1e-12 the SAME resident circuit continues (no reset) and then follows the oracle started
+    from the same state."""
+    meta, gx, deck = golden("bridge_gmin0_fail")
+    eng.set_options(g_min=0.0)
+    eng.load_deck(deck)
+    eng.reset()
+    st = eng.analyze_tr(meta["dt"], meta["steps"], check=False)
+    assert st["rc"] in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_NO_CONVERGENCE)
+    s0 = eng.state()
+    n_ok = int(s0["steps"][0])
+    assert abs(float(s0["t"][0]) - n_ok * meta["dt"]) < 1e-12
+    eng.set_options(g_min=1e-12)
+    st2 = eng.analyze_tr(meta["dt"], 200, check=False)
+    assert st2["rc"] == 0 and st2["steps"] == 200
+    s1 = eng.state()
+    assert s1["status"][0] == 0 and abs(float(s1["t"][0]) - (n_ok + 200) * meta["dt"]) < 1e-12
+    # the continuation is a valid transient of the g_min = 1e-12 bridge: a fresh engine run with that g_min from t = 0 reaches the
+    # same state (the first n_ok steps differ by g_min * v ~ 1e-11 A only)
+    x_cont = eng.solution()[0].copy()
+    e2 = pe.ffi.Engine(device=0)
+    try:
+        e2.set_options(g_min=1e-12)
+        e2.load_deck(deck)
+        e2.reset()
+        e2.analyze_tr(meta["dt"], n_ok + 200)
+        assert max_err(x_cont, e2.solution()[0], 1e-6, 1e-5) <= 1.0
+    finally:
+        e2.close()
+
+
 def test_floating_network_reports_singular(eng):
     """test/0003.circuits/operations.cpp: R || C with no ground, DC.  Must not crash; this engine reports the
     singular system (the reference's Eigen path happens to return x = 0 for the all-zero right-hand side)."""
@@ -200,6 +232,19 @@ def test_solve_csr_real_seam(eng, oracle_mod):
     assert np.max(np.abs(A @ x - b)) < 1e-12
     x2, _ = eng.solve_csr(A.shape[0], A.indptr, A.indices, A.data * 2.0, b, copy_pattern=False)  # cached pattern
     assert np.max(np.abs(2.0 * x2 - xr)) < 1e-9
+
+
+def test_solve_csr_real_seam_large_front(eng):
+    """The seam with one dense front of order 450 (> the default LDS reserve behind the panels): the same LDS-fit escalation
+    as the resident circuit path (round-1 advisor finding)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(7)
+    n = 450
+    A = sp.csr_matrix(rng.standard_normal((n, n)) + n * np.eye(n))
+    A.sort_indices()
+    b = rng.standard_normal(n)
+    x, _ = eng.solve_csr(n, A.indptr, A.indices, A.data, b, copy_pattern=True)
+    assert np.max(np.abs(A @ x - b)) < 1e-9
 
 
 def test_stamped_matrix_matches_oracle(eng, oracle_mod):

@@ -220,3 +220,57 @@ i = eng.info()
 assert i['lds_bytes'] <= 163840 and i['max_front'] > 150 and i['n_top_levels'] > 16
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
+
+
+def test_solver_seam_large_front_under_host_emulation(emu_lib):
+    """solve_csr_real with ONE dense front of order 450 and with a 2-D mesh whose top separator exceeds the default LDS
+    reserve: the seam runs the same LDS-fit escalation as the resident circuit (round-1 advisor finding: an LDS overrun past
+    ~376 rows).  The emulation build asserts `front image + right-hand-side column <= region` in front_factor."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla, pe_load
+pe = pe_load.load()
+rng = np.random.default_rng(7)
+n = 450
+A = sp.csr_matrix(rng.standard_normal((n, n)) + n * np.eye(n)); A.sort_indices()
+b = rng.standard_normal(n)
+eng = pe.ffi.Engine()
+x, _ = eng.solve_csr(n, A.indptr, A.indices, A.data, b, copy_pattern=True)
+assert np.max(np.abs(A @ x - b)) < 1e-9
+# 5-point Laplacian on a 70 x 70 grid + a dense 400-clique coupling block on the diagonal: fronts of several hundred rows
+g = 70
+L = sp.kron(sp.eye(g), sp.diags([-1, 4.5, -1], [-1, 0, 1], shape=(g, g))) + sp.kron(sp.diags([-1, -1], [-1, 1], shape=(g, g)), sp.eye(g))
+L = sp.csr_matrix(L); L.sort_indices()
+b2 = rng.standard_normal(g * g)
+x2, _ = eng.solve_csr(g * g, L.indptr, L.indices, L.data, b2, copy_pattern=True)
+assert np.max(np.abs(x2 - spla.splu(L.tocsc()).solve(b2))) < 1e-9
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=600)
+
+
+def test_failed_solve_is_not_sticky_under_host_emulation(emu_lib):
+    """circuit.h:242-254: a failed transient rolls tr_duration back and returns false; the NEXT analyze() tries again from that
+    state.  Here: the g_min = 0 bridge fails (singular with all four diodes off), the caller raises g_min, and the same resident
+    circuit continues from the rolled-back time (round-1 advisor finding: the failure used to be permanent until a reset)."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))
+import numpy as np
+from parity_common import golden, pe
+meta, gx, deck = golden('bridge_gmin0_fail')
+eng = pe.ffi.Engine(); eng.set_options(g_min=0.0); eng.load_deck(deck); eng.reset()
+st = eng.analyze_tr(meta['dt'], meta['steps'], check=False)
+assert st['rc'] in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_NO_CONVERGENCE)
+s0 = eng.state(); t_fail = float(s0['t'][0]); n_ok = int(s0['steps'][0])
+assert abs(t_fail - n_ok * meta['dt']) < 1e-12
+eng.set_options(g_min=1e-12)
+st2 = eng.analyze_tr(meta['dt'], 50, check=False)
+assert st2['rc'] == 0 and st2['steps'] == 50, st2
+s1 = eng.state()
+assert s1['status'][0] == 0 and abs(float(s1['t'][0]) - (n_ok + 50) * meta['dt']) < 1e-12
+assert np.all(np.isfinite(eng.solution()[0]))
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
