@@ -20,6 +20,11 @@ namespace
     thread_local std::string g_err;
 
     void set_err(std::string s) { g_err = std::move(s); }
+}  // namespace
+// (used by pe_dll_stubs.cpp: the refusing entry points report through the same thread-local message)
+void pe_dll_set_error(std::string const& s) { g_err = s; }
+namespace
+{
 
     // element code -> model; properties are consumed positionally (src/dll_main.cpp:1707-1830, appendix C of SURVEY.md)
     bool add_element(pe::netlist::netlist& nl, int code, double const*& prop, pe::netlist::add_model_retstr& out)

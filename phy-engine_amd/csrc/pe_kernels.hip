@@ -15,6 +15,10 @@
 // Small-signal AC runs the same kernels on the real-equivalent 2N system (pe_ac.cpp).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
 
@@ -687,9 +691,19 @@ namespace pe
         if(bits) atomicOr(V.flags + b, bits);
     }
 
+    // hipFuncAttributeMaxDynamicSharedMemorySize is a per-function upper bound: raised when a launch needs more than any launch
+    // before it, never per launch (a Newton iteration of the split schedule is ~16 launches; engines on several host threads
+    // share the table)
     static hipError_t set_lds(void const* fn, size_t bytes)
     {
-        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        static std::mutex mu;
+        static std::unordered_map<void const*, size_t> allowed;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = allowed.find(fn);
+        if(it != allowed.end() && bytes <= it->second) return hipSuccess;
+        hipError_t const e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+        if(e == hipSuccess) allowed[fn] = bytes;
+        return e;
     }
 
     hipError_t launch_tr_steps(hipStream_t st, DevView const& V, double dt, int nsteps, bool reuse)
@@ -769,7 +783,8 @@ namespace pe
             if(ev0) (void)hipEventRecord(ev0, st);
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
-            bool const wide = MINW == 2 && getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;  // one workgroup per CU anyway (LDS plan); (developer knob for A/B runs)
+            static bool const wide_knob = getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;
+            bool const wide = MINW == 2 && wide_knob;  // one workgroup per CU anyway (LDS plan); (developer knob for A/B runs)
             for(int l = 0; l < V.n_top_levels; l += run(l))
             {
                 if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), lds, st, V, l, run(l));

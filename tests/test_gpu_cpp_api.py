@@ -1,9 +1,8 @@
 """GPU: the C++ plug-in API mirror (phy-engine_amd/include/phy_engine) and the FFI loader subset
 (include/phy_engine_dll_api.h), exercised by reference-style test programs (tests/cpp/*.cpp: one main() per file,
-exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64).  Each mirrors a test of the reference:
-  rc_step_tr      test/0005.models/rc_step_tr.cpp
-  dc_divider      test/0004.solver/dc.cpp
-  op_pn_junction  test/0011.nonlinear/op_pn_junction.cpp
+exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64):
+  known_answers   own netlists with closed-form answers: the 3 V / 10 + 20 ohm string (3 V, 2 V, 0.1 A), RC charging to 1 - 1/e,
+                  the diode operating point (KCL with the Shockley law; the real reference's 0.62944165 V)
   bridge_tr       config C2 through full_bridge_rectifier + refusal of a host-only user model
   dll_smoke       test/0008.dll/dll_main_smoke.cpp
   linear_models   the known answers of test/0005.models/{vccs_dc,vcvs_gain,cccs_dc,ccvs_dc,op_amp_follower,transformer_ratio,
@@ -19,7 +18,7 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["rc_step_tr", "dc_divider", "op_pn_junction", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
+TESTS = ["known_answers", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")

@@ -20,6 +20,63 @@ def test_library_exports_every_header_symbol(pe):
     assert sorted(pe.ffi.EXPORTS) == declared
 
 
+def test_library_exports_every_loader_symbol(pe):
+    """Every function include/phy_engine_dll_api.h declares (the loader subset AND the refusing out-of-scope entry points) is
+    exported by libpe_hip.so; the refusing ones set the error message and return their failure value (no GPU needed)."""
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "phy_engine_dll_api.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b([a-z][a-z_0-9]+)\s*\(", body)) - {"defined", "sizeof"})
+    assert len(declared) >= 90, declared
+    lib = pe.ffi.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/phy_engine_dll_api.h but not exported by libpe_hip.so"
+    lib.phy_engine_last_error.restype = C.c_char_p
+    lib.verilog_runtime_create.restype = C.c_void_p
+    lib.phy_engine_clear_error()
+    assert lib.verilog_runtime_create(b"", 0, b"", 0, None, None, 0) is None
+    assert b"verilog_runtime_create" in lib.phy_engine_last_error()
+    lib.pl_experiment_create.restype = C.c_void_p
+    assert lib.pl_experiment_create(0) is None and b"pl_experiment_create" in lib.phy_engine_last_error()
+    assert lib.pl_pe_circuit_analyze(None) != 0
+    lib.verilog_synth_get_loop_unroll_limit.restype = C.c_size_t
+    assert lib.verilog_synth_get_loop_unroll_limit() == 64  # src/dll_main.cpp:61
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/python/phy_engine"), reason="build container only: the reference's ctypes client is never copied or shipped")
+def test_reference_ctypes_client_binds_and_runs(emu_lib):
+    """the reference's own Python client (python/phy_engine, imported in place from /root/reference) binds
+    all 90 symbols of libpe_hip.so, and -- against the loader built on the host emulation, since this container has no GPU --
+    drives create_circuit -> circuit_analyze -> circuit_sample on the known answer of test/0008.dll/dll_main_smoke.cpp
+    (VDC 5 V across 1 kOhm: 5 V, 5 mA), and gets a loud refusal from an out-of-scope entry point."""
+    emu_dir = os.path.dirname(emu_lib)
+    subprocess.run(["make", "-C", emu_dir, "libphyengine_emu.so"], check=True, capture_output=True)
+    product = os.path.join(ROOT, "phy-engine_amd", "libpe_hip.so")
+    code = f"""
+import ctypes as ct, os, sys
+sys.path.insert(0, '/root/reference/python')
+os.environ['PHY_ENGINE_LIB'] = {os.path.join(emu_dir, 'libphyengine_emu.so')!r}
+import phy_engine
+from phy_engine import _ffi
+_ffi._configure_library(ct.CDLL({product!r}))          # the product library: every symbol the client binds exists
+E, W = phy_engine.Element, phy_engine.Wire
+# elements: 0 = VDC 5 V, 1 = R 1 kOhm, 2 = ground placeholder; wires (ele, pin, ele, pin)
+c = phy_engine.Circuit([E(4, (5.0,)), E(1, (1000.0,)), E(0)], [W(0, 0, 1, 0), W(0, 1, 1, 1), W(0, 1, 2, 0)])
+c.set_analyze_type(phy_engine.AnalyzeType.DC)
+s = c.analyze_and_sample()
+vdc, res = s.components
+assert abs(abs(vdc.pin_voltages[0] - vdc.pin_voltages[1]) - 5.0) < 1e-9, s
+assert abs(abs(vdc.branch_currents[0]) - 5e-3) < 1e-12, s
+c.close()
+try:
+    phy_engine.VerilogRuntime('module top; endmodule')
+    raise SystemExit('the Verilog runtime must refuse')
+except phy_engine.PhyEngineError as e:
+    assert 'not available' in str(e), e
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
 def test_no_silent_cpu_fallback(pe):
     """Without a HIP device the engine must refuse to exist (no CPU numeric path in the product)."""
     if pe.ffi.lib().pe_hip_device_count() > 0:
