@@ -168,6 +168,28 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out);
  * drive set with new voltages updates in place; a different set invalidates the resident circuit (reload it). */
 int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, const double* volt);
 
+/* ---- Host-stamp overlay: plug-in models WITHOUT a device table.
+ * The reference's extension mechanism is the per-model stamp hook (iterate_{dc,tr,op,trop}_define(tag, M&, MNA&[, t]) with the
+ * fallback chains of model/model_refs/base.h:216-304, called in the model loop of circult::solve_once, circuit.h:1071-1084).
+ * A user model that only has those hooks is evaluated ON THE HOST, once per Newton iteration, into a fixed set of matrix
+ * cells / right-hand-side rows discovered once (what mna_keep_pattern_ready does, circuit.h:993-1003); the values are uploaded
+ * and ADDED to the device-side stamp.  The hooks read node voltages, so the Newton loop of such a circuit is driven from the
+ * host (one callback + one small upload per iteration); batch must be 1.
+ *   rows / cols / rhs_rows  absolute MNA indices, 0-based: nodes 0 .. n_nodes-1, then branches (mna.h:60-157 G/B/C/D/I/E layout)
+ *   representative          |value| per cell for the static pivot matching (the discovery stamp), may be NULL
+ *   nonlinear               1: the circuit needs Newton iterations even without a built-in non-linear device
+ *   fn(user, event, mode, t, dt, x, a_values, b_values) -> 0 ok, else the analysis fails with PE_HIP_ERR_INTERNAL:
+ *     PE_HIP_OVERLAY_STEP     start of a transient step, x = solution of the previous time point, dt = new step (the models'
+ *                             step_changed_tr hooks; circult::update_tr_step, circuit.h:363-374); a_values / b_values NULL
+ *     PE_HIP_OVERLAY_ITERATE  before the stamp of every Newton iteration, x = current iterate: fill a_values[n_cells] and
+ *                             b_values[n_rhs] (mode = pe_hip_mode of the solve, t = time of the point being solved)
+ * Call before pe_hip_load_circuit() (the cells are part of the sparsity pattern); n_cells = n_rhs = 0 with fn = NULL removes it. */
+#define PE_HIP_OVERLAY_STEP 0
+#define PE_HIP_OVERLAY_ITERATE 1
+typedef int (*pe_hip_overlay_fn)(void* user, int event, int mode, double t, double dt, const double* x, double* a_values, double* b_values);
+int pe_hip_set_overlay(pe_hip_engine* h, int n_cells, const int* rows, const int* cols, const double* representative, int n_rhs, const int* rhs_rows,
+                       int nonlinear, pe_hip_overlay_fn fn, void* user);
+
 /* overwrite one parameter column of one device for every instance (values: [batch] if batched else [1]) */
 int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const double* values, int batched);
 

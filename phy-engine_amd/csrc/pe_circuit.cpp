@@ -152,7 +152,7 @@ namespace pe
     }
 
     bool build_circuit(int n_nodes, int n_branches, int batch, int n_tables, pe_hip_device_table const* tables, int n_drives, int const* drv_node,
-                       double const* drv_volt, HostCircuit& hc)
+                       double const* drv_volt, HostCircuit& hc, OverlaySpec const* overlay)
     {
         hc = HostCircuit{};
         if(n_nodes < 0 || n_branches < 0 || batch < 1 || n_drives < 0 || n_drives > n_branches)
@@ -447,6 +447,33 @@ namespace pe
         hc.dv_dg = o; o += hc.nD();
         hc.dv_di = o; o += hc.nD();
         hc.dv_drv = o; o += n_drives;
+        if(overlay)
+        {
+            if(batch != 1 && !overlay->empty())
+            {
+                hc.error = "a host-stamp overlay needs batch = 1";
+                return false;
+            }
+            for(size_t i = 0; i < overlay->rows.size(); ++i)
+                if(overlay->rows[i] < 0 || overlay->rows[i] >= hc.rows || overlay->cols[i] < 0 || overlay->cols[i] >= hc.rows)
+                {
+                    hc.error = "overlay cell out of range";
+                    return false;
+                }
+            for(int r: overlay->rhs_rows)
+                if(r < 0 || r >= hc.rows)
+                {
+                    hc.error = "overlay right-hand-side row out of range";
+                    return false;
+                }
+            hc.n_ov_a = static_cast<int>(overlay->rows.size());
+            hc.n_ov_b = static_cast<int>(overlay->rhs_rows.size());
+            hc.ov_rep = overlay->rep;
+            hc.ov_rep.resize(hc.n_ov_a, 1.0);
+            hc.nonlinear = hc.nonlinear || overlay->nonlinear;
+        }
+        hc.dv_ova = o; o += hc.n_ov_a;
+        hc.dv_ovb = o; o += hc.n_ov_b;
         hc.dv_gen = o;
         for(auto& d: hc.gen)
         {
@@ -685,6 +712,9 @@ namespace pe
                     break;
             }
         }
+        // host-stamped models (the reference runs them in the same model loop; their cells only ever accumulate)
+        for(int i = 0; i < hc.n_ov_a; ++i) A_add(overlay->rows[i], overlay->cols[i], hc.dv_ova + i, false);
+        for(int i = 0; i < hc.n_ov_b; ++i) B_add(overlay->rhs_rows[i], hc.dv_ovb + i, false);
         for(int n = 0; n < N; ++n) A_add(n, n, DV_GMIN, false);  // circuit.h:1107-1110
 
         // ---- CSR pattern
@@ -739,6 +769,7 @@ namespace pe
         dv[DV_ONE] = 1.0;
         dv[DV_GMIN] = gmin;
         for(int i = 0; i < hc.nR(); ++i) dv[hc.dv_r + i] = hc.r_g[i];
+        for(int i = 0; i < hc.n_ov_a; ++i) dv[hc.dv_ova + i] = hc.ov_rep[i];
         bool const dyn = tr_mode && dt > 0.0;
         for(int i = 0; i < hc.nC(); ++i) dv[hc.dv_cg + i] = dyn ? 2.0 * hc.c_cap[i] / dt : 0.0;
         for(int i = 0; i < hc.nL(); ++i) dv[hc.dv_lr + i] = dyn ? -2.0 * hc.l_ind[i] / dt : 0.0;

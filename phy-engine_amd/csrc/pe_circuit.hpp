@@ -38,6 +38,9 @@ namespace pe
         std::vector<int> a_ptr, a_src;
         std::vector<int> b_ptr, b_src;
         bool nonlinear{};
+        // host-stamp overlay: dv slots [dv_ova, dv_ova + n_ov_a) add into the cells (ov_rows, ov_cols), [dv_ovb, ..) into the rhs rows
+        int n_ov_a{}, n_ov_b{}, dv_ova{}, dv_ovb{};
+        std::vector<double> ov_rep;
         std::string error;
 
         // ---- the remaining linear stampers (PE_HIP_IAC .. PE_HIP_COUPLED_L), kept in one generic list
@@ -77,9 +80,20 @@ namespace pe
         int nD() const { return static_cast<int>(d_a.size()); }
     };
 
+    // Host-stamp overlay (pe_hip_set_overlay): matrix cells / right-hand-side rows whose values come from the host once per
+    // Newton iteration (plug-in models without a device table).  Each entry owns one dv slot and ADDS it to its cell.
+    struct OverlaySpec
+    {
+        std::vector<int> rows, cols;   // absolute MNA indices (0-based: nodes first, then branches)
+        std::vector<double> rep;       // representative values for the row matching
+        std::vector<int> rhs_rows;
+        bool nonlinear{};
+        bool empty() const { return rows.empty() && rhs_rows.empty(); }
+    };
+
     // Build from C-ABI tables.  drives: digital_out sources occupying branches [0, n_drives).
     bool build_circuit(int n_nodes, int n_branches, int batch, int n_tables, pe_hip_device_table const* tables, int n_drives, int const* drv_node,
-                       double const* drv_volt, HostCircuit& hc);
+                       double const* drv_volt, HostCircuit& hc, OverlaySpec const* overlay = nullptr);
 
     // generic kinds: pins, branch rows, raw parameter columns, dv slots
     int gen_pins(int kind);

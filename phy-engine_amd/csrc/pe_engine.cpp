@@ -89,6 +89,10 @@ struct pe_hip_engine
     pe::HostCircuit hc;
     std::vector<int> drv_node;
     std::vector<double> drv_volt;
+    pe::OverlaySpec overlay;      // host-stamp overlay (pe_hip_set_overlay): part of the pattern of the next load
+    pe_hip_overlay_fn overlay_fn{};
+    void* overlay_user{};
+    std::vector<double> ov_x, ov_a, ov_b;  // staging of the callback
     Pool circ_pool;  // topology, params, state
     Pool sym_pool;   // symbolic arrays + factor storage
     pe::Symbolic sym;
@@ -158,8 +162,30 @@ namespace
         char const* v = std::getenv("PHY_ENGINE_HIP_SPLIT");  // knob: 1 = always split, 0 = never (resident kernel, one part)
         if(v && *v == '1') return true;
         if(v && *v == '0') return false;
+        if(h->overlay_fn && (h->hc.n_ov_a || h->hc.n_ov_b)) return true;  // host-stamped models: the host drives the Newton loop
         return h->V.n_parts > 1 || h->hc.rows >= 3000;
     }
+
+    // host-stamp overlay: one callback (+ the upload of its values for ITERATE) on instance 0's current x
+    int overlay_call(pe_hip_engine* h, int event, int mode, double t, double dt)
+    {
+        auto const& hc = h->hc;
+        h->ov_x.resize(static_cast<size_t>(hc.rows));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if(hc.rows) HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
+        bool const iter = event == PE_HIP_OVERLAY_ITERATE;
+        h->ov_a.assign(static_cast<size_t>(hc.n_ov_a), 0.0);
+        h->ov_b.assign(static_cast<size_t>(hc.n_ov_b), 0.0);
+        if(h->overlay_fn(h->overlay_user, event, mode, t, dt, h->ov_x.data(), iter ? h->ov_a.data() : nullptr, iter ? h->ov_b.data() : nullptr) != 0)
+            return fail(h, PE_HIP_ERR_INTERNAL, "host-stamp overlay: a model hook failed");
+        if(iter)
+        {
+            if(hc.n_ov_a) HIPCHK(h, hipMemcpy(h->V.dv + hc.dv_ova, h->ov_a.data(), static_cast<size_t>(hc.n_ov_a) * sizeof(double), hipMemcpyHostToDevice));
+            if(hc.n_ov_b) HIPCHK(h, hipMemcpy(h->V.dv + hc.dv_ovb, h->ov_b.data(), static_cast<size_t>(hc.n_ov_b) * sizeof(double), hipMemcpyHostToDevice));
+        }
+        return PE_HIP_OK;
+    }
+    bool has_overlay(pe_hip_engine const* h) { return h->overlay_fn && (h->hc.n_ov_a || h->hc.n_ov_b); }
 
     double r_open_of(pe_hip_engine const* h) { return h->opt.r_open > 0.0 ? h->opt.r_open : 1e12; }  // circuit.h:1012
 
@@ -299,6 +325,8 @@ namespace
         {
             so.n_parts = batch >= 192 ? 4 : (batch >= 96 ? 8 : std::clamp(256 / std::max(1, batch), 1, 48));
             so.part_cut = 1.0;
+            so.nd_leaf = 10;  // finer dissection: fewer, better-shaped fronts on big meshes (-3.6 % per iteration on M10k, profiles/sweep_r02_leaf.log);
+                              // small circuits keep 24 (their whole graph is one minimum-degree leaf, as validated by every golden)
         }
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
         auto env_int = [](char const* name, int def)
@@ -547,6 +575,8 @@ namespace
         int const max_it = h->hc.nonlinear ? h->V.max_newton : 1;
         for(int it = 0; it < max_it && n_active > 0; ++it)
         {
+            if(has_overlay(h))
+                if(int const rc = overlay_call(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step); rc != PE_HIP_OK) return rc;
             HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1));
             ++launches;
@@ -588,7 +618,7 @@ namespace
         int rc = m2_pull(h, S);
         if(rc != PE_HIP_OK) return rc;
         int const B = h->hc.batch;
-        bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve;
+        bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve && !has_overlay(h);  // (overlay values may change every solve)
         std::vector<int> res;
         for(int s = 0; s < nsteps; ++s)
         {
@@ -599,6 +629,8 @@ namespace
                 alive += S.active[b];
             }
             if(!alive) break;
+            if(has_overlay(h))
+                if(int const orc = overlay_call(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt); orc != PE_HIP_OK) return orc;
             HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
@@ -750,6 +782,27 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
     return PE_HIP_OK;
 }
 
+int pe_hip_set_overlay(pe_hip_engine* h, int n_cells, const int* rows, const int* cols, const double* representative, int n_rhs, const int* rhs_rows,
+                       int nonlinear, pe_hip_overlay_fn fn, void* user)
+{
+    if(!h || n_cells < 0 || n_rhs < 0 || (n_cells > 0 && (!rows || !cols)) || (n_rhs > 0 && !rhs_rows)) return PE_HIP_ERR_ARG;
+    if((n_cells > 0 || n_rhs > 0) && !fn) return fail(h, PE_HIP_ERR_ARG, "set_overlay: cells without a callback");
+    pe::OverlaySpec next;
+    next.rows.assign(rows, rows + n_cells);
+    next.cols.assign(cols, cols + n_cells);
+    if(representative) next.rep.assign(representative, representative + n_cells);
+    next.rhs_rows.assign(rhs_rows, rhs_rows + n_rhs);
+    next.nonlinear = nonlinear != 0;
+    // the cells are part of the sparsity pattern: a different set invalidates the resident circuit (reload it), as a different
+    // set of digital drives does
+    if(h->loaded && (next.rows != h->overlay.rows || next.cols != h->overlay.cols || next.rhs_rows != h->overlay.rhs_rows || next.nonlinear != h->overlay.nonlinear))
+        h->loaded = false;
+    h->overlay = std::move(next);
+    h->overlay_fn = fn;
+    h->overlay_user = user;
+    return PE_HIP_OK;
+}
+
 int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, const double* volt)
 {
     if(!h || count < 0 || (count > 0 && (!node || !volt))) return PE_HIP_ERR_ARG;
@@ -791,7 +844,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
         h->ac = pe_hip_engine::Ac{};
     }
     if(!pe::build_circuit(n_nodes, n_branches, batch, n_tables, tables, static_cast<int>(h->drv_node.size()), h->drv_node.data(),
-                          h->drv_volt.data(), h->hc))
+                          h->drv_volt.data(), h->hc, h->overlay.empty() ? nullptr : &h->overlay))
         return fail(h, PE_HIP_ERR_ARG, "load_circuit: " + h->hc.error);
     return finish_load(h);
 }
@@ -991,7 +1044,7 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
     std::vector<long long> s0, i0;
     rc = snapshot_counters(h, s0, i0);
     if(rc != PE_HIP_OK) return rc;
-    bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve;
+    bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve && !has_overlay(h);
     int const chunk = h->hc.rows > 2000 ? 32 : (h->hc.rows > 200 ? 256 : 2048);
     int launches = 0;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
@@ -1462,6 +1515,7 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     if(st) std::memset(st, 0, sizeof(*st));
     auto& hc = h->hc;
     if(hc.rows == 0) return PE_HIP_OK;
+    if(has_overlay(h)) return fail(h, PE_HIP_ERR_ARG, "analyze_ac: host-stamped models (pe_hip_set_overlay) have no small-signal path in this engine");
     auto& A = h->ac;
     if(!A.built)
     {

@@ -23,7 +23,7 @@ OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL = 0, 
 
 EXPORTS = [
     "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real",
-    "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_update_param",
+    "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
     "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",

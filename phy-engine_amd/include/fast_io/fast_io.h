@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "fast_io_dsal/string_view.h"
+#include "fast_io_dsal/vector.h"
 
 namespace fast_io
 {

@@ -56,6 +56,21 @@ namespace phy_engine::model
         t.row[0] = {PE_HIP_R, 0, 1, -1, {m.r}};
         return true;
     }
+    // The reference's host stamp (linear/resistance.h:82-110): the conductance 1/r on the four G cells of its two nodes.  The
+    // engine itself stamps built-in models from their device tables; the hook is part of the model's interface
+    // (defines::can_iterate_dc) and is what a wrapper model without a table of its own would forward to.
+    inline bool iterate_dc_define(model_reserve_type_t<resistance>, resistance const& m, ::phy_engine::MNA::MNA& mna) noexcept
+    {
+        auto const* a = m.pins[0].nodes;
+        auto const* b = m.pins[1].nodes;
+        if(!a || !b) return true;
+        double const g = 1.0 / m.r;
+        mna.G_ref(a->node_index, a->node_index) += g;
+        mna.G_ref(a->node_index, b->node_index) -= g;
+        mna.G_ref(b->node_index, a->node_index) -= g;
+        mna.G_ref(b->node_index, b->node_index) += g;
+        return true;
+    }
 
     // ------------------------------------------------------------------ capacitor (linear/capacitor.h)
     struct capacitor
@@ -193,7 +208,21 @@ namespace phy_engine::model
         double Area{1.0};
         double tt{0.0};
         pin pins[2]{{{u8"A"}}, {{u8"B"}}};
+        // derived by prepare_foundation_define from the public parameters, which it never modifies (PN_junction.h:296-354)
+        double Is_eff{}, Isr_eff{}, Ut{}, Uth{}, Bv_eff{};
     };
+    // PN_junction.h:296-354 with the reference's constants (the device derives the same quantities from the table row:
+    // pe::diode_derive, pe_circuit.cpp); the public parameters are never modified
+    inline bool prepare_foundation_define(model_reserve_type_t<PN_junction>, PN_junction& m) noexcept
+    {
+        m.Is_eff = m.Is * m.Area;
+        m.Isr_eff = m.Isr * m.Area;
+        m.Ut = 1.380650524e-23 * (m.Temp + 273.15) / 1.6021765314e-19;
+        double const nut = m.N * m.Ut;
+        m.Bv_eff = m.Bv_set ? m.Bv - nut * ::std::log(m.Ibv / m.Is_eff) : m.Bv;
+        m.Uth = nut * ::std::log(nut / (1.4142135623730950488016887242096981 * m.Is_eff));
+        return true;
+    }
     inline bool set_attribute_define(model_reserve_type_t<PN_junction>, PN_junction& m, ::std::size_t n, variant vi) noexcept
     {
         double PN_junction::* const f[10] = {&PN_junction::Is, &PN_junction::N, &PN_junction::Isr, &PN_junction::Nr, &PN_junction::Temp, &PN_junction::Ibv,

@@ -21,6 +21,7 @@
 #include <concepts>
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <memory>
 #include <set>
 #include <string>
@@ -28,6 +29,7 @@
 #include <type_traits>
 #include <vector>
 
+#include <fast_io/fast_io.h>
 #include <fast_io/fast_io_dsal/string_view.h>
 
 #include "../../../include/pe_hip.h"
@@ -269,15 +271,61 @@ namespace phy_engine
         };
     }  // namespace model
 
-    // ---- circuits/MNA/mna.h: kept for source compatibility of user hooks (iterate_*_define(tag, M&, MNA&)); the
-    // GPU-resident path never fills it
+    // ---- circuits/MNA/mna.h:12-169: the sparse system the stamp hooks write into -- rows of (column -> value) maps plus the
+    // right-hand side Z, with the G / B / C / D / I / E views over [nodes | branches] and the "index SIZE_MAX = ground, write
+    // into a scratch cell" rule (mna.h:62).  On the MI355X path the built-in models never touch it (their stamps are device
+    // tables); it carries (1) the stamps of plug-in models that only have host hooks (the overlay circult::prepare builds and
+    // the engine adds every Newton iteration), and (2) after an analysis of a small circuit, a copy of the last assembled
+    // system for inspection (circult::mna, as tests of the reference dump it).
     namespace MNA
     {
         struct MNA
         {
+            using value_type = ::std::complex<double>;
+            using row_type = ::std::map<::std::size_t, value_type>;
+
+            MNA() noexcept = default;
+            MNA(::std::size_t ns, ::std::size_t bs) : node_size{ns}, branch_size{bs} { A.resize(ns + bs); }
+            void resize(::std::size_t ns, ::std::size_t bs)
+            {
+                node_size = ns;
+                branch_size = bs;
+                A.resize(ns + bs);
+            }
+            void clear() noexcept
+            {
+                for(auto& row: A) row.clear();
+                Z.clear();
+            }
+            // keeps the cells (the pattern only ever grows), zeroes the values
+            void clear_values_keep_pattern() noexcept
+            {
+                for(auto& row: A)
+                    for(auto& kv: row) kv.second = {};
+                for(auto& kv: Z) kv.second = {};
+            }
+            void clear_destroy() noexcept { clear(); }
+
+            value_type& A_ref(::std::size_t row, ::std::size_t col) { return (row == SIZE_MAX || col == SIZE_MAX) ? scratch_ : A[row][col]; }
+            value_type& G_ref(::std::size_t row, ::std::size_t col) { return A_ref(row, col); }
+            value_type& B_ref(::std::size_t row, ::std::size_t col) { return (row == SIZE_MAX || col == SIZE_MAX) ? scratch_ : A[row][col + node_size]; }
+            value_type& C_ref(::std::size_t row, ::std::size_t col) { return (row == SIZE_MAX || col == SIZE_MAX) ? scratch_ : A[row + node_size][col]; }
+            value_type& D_ref(::std::size_t row, ::std::size_t col)
+            {
+                return (row == SIZE_MAX || col == SIZE_MAX) ? scratch_ : A[row + node_size][col + node_size];
+            }
+            value_type& Z_ref(::std::size_t row) { return row == SIZE_MAX ? scratch_ : Z[row]; }
+            value_type& I_ref(::std::size_t row) { return Z_ref(row); }
+            value_type& E_ref(::std::size_t row) { return row == SIZE_MAX ? scratch_ : Z[row + node_size]; }
+
+            ::std::vector<row_type> A{};
+            row_type Z{};
             ::std::size_t node_size{};
             ::std::size_t branch_size{};
             double r_open{1e12};
+
+        private:
+            value_type scratch_{};
         };
     }  // namespace MNA
 
@@ -377,6 +425,54 @@ namespace phy_engine
                 { prepare_foundation_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
             };
             template <typename mod>
+            concept can_init = requires(mod&& t) {
+                { init_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_highest_priority = requires(mod&& t) {
+                { prepare_highest_priority_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_ac = requires(mod&& t) {
+                { prepare_ac_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_dc = requires(mod&& t) {
+                { prepare_dc_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_tr = requires(mod&& t) {
+                { prepare_tr_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_op = requires(mod&& t) {
+                { prepare_op_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_prepare_trop = requires(mod&& t) {
+                { prepare_trop_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_save_op = requires(mod&& t) {
+                { save_op_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_load_temperature = requires(mod&& t) {
+                { load_temperature_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, double{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_adapt_step = requires(mod&& t, double step) {
+                { adapt_step_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, step) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_check_convergence = requires(mod&& t) {
+                { check_convergence_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
+            concept can_query_status = requires(mod&& t) {
+                { query_status_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, ::std::size_t{}) } -> ::std::same_as<bool>;
+            };
+            template <typename mod>
             concept can_iterate_ac = requires(mod&& t, ::phy_engine::MNA::MNA& mna) {
                 { iterate_ac_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, mna, double{}) } -> ::std::same_as<bool>;
             };
@@ -419,6 +515,8 @@ namespace phy_engine
             template <typename mod>
             concept has_get_attribute_name = has_full_get_attribute_name<mod> || has_reduced_get_attribute_name<mod>;
             template <typename mod>
+            concept has_attribute = has_set_attribute<mod> && has_get_attribute<mod> && has_get_attribute_name<mod>;
+            template <typename mod>
             concept can_generate_pin_view = requires(mod&& t) {
                 { generate_pin_view_define(model_reserve_type<::std::remove_cvref_t<mod>>, t) } -> ::std::same_as<pin_view>;
             };
@@ -434,9 +532,11 @@ namespace phy_engine
             concept can_gpu_table = requires(mod const& t, gpu_table_rows& rows) {
                 { gpu_table_define(model_reserve_type<::std::remove_cvref_t<mod>>, t, rows) } -> ::std::same_as<bool>;
             };
+            // a model the HOST can stamp: the reference's own notion of can_iterate_mna (concept.h:183)
             template <typename mod>
-            concept can_iterate_mna =
-                can_iterate_ac<mod> || can_iterate_dc<mod> || can_iterate_op<mod> || can_iterate_tr<mod> || can_iterate_trop<mod> || can_gpu_table<mod>;
+            concept can_host_stamp = can_iterate_ac<mod> || can_iterate_dc<mod> || can_iterate_op<mod> || can_iterate_tr<mod> || can_iterate_trop<mod>;
+            template <typename mod>
+            concept can_iterate_mna = can_host_stamp<mod> || can_gpu_table<mod>;
             template <typename mod>
             concept can_update_digital_clk = requires(mod&& t, ::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) {
                 {
@@ -481,6 +581,21 @@ namespace phy_engine
                 virtual model_device_type get_device_type() noexcept = 0;
                 virtual bool has_gpu_table() noexcept = 0;
                 virtual bool gpu_table(gpu_table_rows& rows) noexcept = 0;
+                // host hooks with the fallback chains of model/model_refs/base.h:103-330 (used for models without a device table)
+                virtual bool has_host_stamp() noexcept = 0;
+                virtual bool init_model() noexcept = 0;
+                virtual bool prepare_for(int analysis) noexcept = 0;  // analyze_type value: prepare_{op,dc,ac,tr,trop} + fallbacks
+                virtual bool iterate_ac(::phy_engine::MNA::MNA& mna, double omega) noexcept = 0;
+                virtual bool iterate_dc(::phy_engine::MNA::MNA& mna) noexcept = 0;
+                virtual bool iterate_tr(::phy_engine::MNA::MNA& mna, double t_time) noexcept = 0;
+                virtual bool iterate_op(::phy_engine::MNA::MNA& mna) noexcept = 0;
+                virtual bool iterate_trop(::phy_engine::MNA::MNA& mna) noexcept = 0;
+                virtual bool save_op() noexcept = 0;
+                virtual bool load_temperature(double temp) noexcept = 0;
+                virtual ::std::size_t find_attribute(::std::u8string_view lower_case_name) noexcept = 0;
+                virtual bool step_changed_tr(double last_step, double now_step) noexcept = 0;
+                virtual bool adapt_step(double& step) noexcept = 0;
+                virtual bool check_convergence() noexcept = 0;
                 virtual ::phy_engine::digital::need_operate_analog_node_t
                     update_digital_clk(::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) noexcept = 0;
                 virtual digital_update_method_t get_digital_update_method() noexcept = 0;
@@ -536,6 +651,162 @@ namespace phy_engine
                     if constexpr(defines::can_gpu_table<T>) return gpu_table_define(model_reserve_type<T>, m, rows);
                     else
                         return false;
+                }
+                bool has_host_stamp() noexcept override { return defines::can_host_stamp<T>; }
+                bool init_model() noexcept override
+                {
+                    if constexpr(defines::can_init<T>) return init_define(model_reserve_type<T>, m);
+                    else
+                        return true;
+                }
+                // base.h:103-215: highest priority first, then the analysis' own hook, its documented fallback, the foundation
+                bool prepare_for(int analysis) noexcept override
+                {
+                    constexpr auto tag = model_reserve_type<T>;
+                    if constexpr(defines::can_prepare_highest_priority<T>) return prepare_highest_priority_define(tag, m);
+                    else
+                    {
+                        auto foundation = [&]() -> bool
+                        {
+                            if constexpr(defines::can_prepare_foundation<T>) return prepare_foundation_define(tag, m);
+                            else
+                                return true;
+                        };
+                        switch(static_cast<analyze_type>(analysis))
+                        {
+                            case analyze_type::AC:
+                            case analyze_type::ACOP:
+                                if constexpr(defines::can_prepare_ac<T>) return prepare_ac_define(tag, m);
+                                else
+                                    return foundation();
+                            case analyze_type::TR:
+                                if constexpr(defines::can_prepare_tr<T>) return prepare_tr_define(tag, m);
+                                else
+                                    return foundation();
+                            case analyze_type::OP:
+                                if constexpr(defines::can_prepare_op<T>) return prepare_op_define(tag, m);
+                                else if constexpr(defines::can_prepare_dc<T>)
+                                    return prepare_dc_define(tag, m);
+                                else
+                                    return foundation();
+                            case analyze_type::TROP:
+                                if constexpr(defines::can_prepare_trop<T>) return prepare_trop_define(tag, m);
+                                else if constexpr(defines::can_prepare_tr<T>)
+                                    return prepare_tr_define(tag, m);
+                                else
+                                    return foundation();
+                            default:
+                                if constexpr(defines::can_prepare_dc<T>) return prepare_dc_define(tag, m);
+                                else
+                                    return foundation();
+                        }
+                    }
+                }
+                // base.h:216-304: ac -> dc; tr -> dc; op -> dc; trop -> tr(0) -> dc; a model with some other stamp hook stamps nothing
+                bool iterate_dc(::phy_engine::MNA::MNA& mna) noexcept override
+                {
+                    if constexpr(defines::can_iterate_dc<T>) return iterate_dc_define(model_reserve_type<T>, m, mna);
+                    else
+                        return defines::can_iterate_mna<T> || defines::is_valid_digital_model<T>;
+                }
+                bool iterate_ac(::phy_engine::MNA::MNA& mna, double omega) noexcept override
+                {
+                    if constexpr(defines::can_iterate_ac<T>) return iterate_ac_define(model_reserve_type<T>, m, mna, omega);
+                    else
+                        return iterate_dc(mna);
+                }
+                bool iterate_tr(::phy_engine::MNA::MNA& mna, double t_time) noexcept override
+                {
+                    if constexpr(defines::can_iterate_tr<T>) return iterate_tr_define(model_reserve_type<T>, m, mna, t_time);
+                    else
+                        return iterate_dc(mna);
+                }
+                bool iterate_op(::phy_engine::MNA::MNA& mna) noexcept override
+                {
+                    if constexpr(defines::can_iterate_op<T>) return iterate_op_define(model_reserve_type<T>, m, mna);
+                    else
+                        return iterate_dc(mna);
+                }
+                bool iterate_trop(::phy_engine::MNA::MNA& mna) noexcept override
+                {
+                    if constexpr(defines::can_iterate_trop<T>) return iterate_trop_define(model_reserve_type<T>, m, mna);
+                    else if constexpr(defines::can_iterate_tr<T>)
+                        return iterate_tr_define(model_reserve_type<T>, m, mna, 0.0);
+                    else
+                        return iterate_dc(mna);
+                }
+                bool save_op() noexcept override
+                {
+                    if constexpr(T::device_type == model_device_type::non_linear && defines::can_save_op<T>) return save_op_define(model_reserve_type<T>, m);
+                    else
+                        return true;
+                }
+                // base.h:326-380: without a hook of its own, a model that exposes a numeric attribute called "Temp" (any case) takes
+                // the environment temperature through set_attribute and re-derives its foundation quantities
+                bool load_temperature(double temp) noexcept override
+                {
+                    if constexpr(defines::can_load_temperature<T>) return load_temperature_define(model_reserve_type<T>, m, temp);
+                    else
+                    {
+                        if constexpr(defines::has_set_attribute<T> && defines::has_get_attribute_name<T>)
+                        {
+                            ::std::size_t const idx{find_attribute(u8"temp")};
+                            if(idx != SIZE_MAX)
+                            {
+                                variant v{};
+                                v.d = temp;
+                                v.type = variant_type::d;
+                                (void)set_attribute(idx, v);
+                                if constexpr(defines::can_prepare_foundation<T>) (void)prepare_foundation_define(model_reserve_type<T>, m);
+                            }
+                        }
+                        return true;
+                    }
+                }
+                // first attribute whose name equals `lower` ignoring ASCII case (the scan limits of base.h:354-372), or SIZE_MAX
+                ::std::size_t find_attribute(::std::u8string_view lower) noexcept override
+                {
+                    ::std::size_t empty_run{};
+                    bool seen{};
+                    for(::std::size_t idx{}; idx < 512; ++idx)
+                    {
+                        auto const n = get_attribute_name(idx);
+                        if(n.empty())
+                        {
+                            if(seen && ++empty_run >= 64) break;
+                            continue;
+                        }
+                        seen = true;
+                        empty_run = 0;
+                        if(n.size() != lower.size()) continue;
+                        bool same{true};
+                        for(::std::size_t i{}; i < lower.size() && same; ++i)
+                        {
+                            auto ch = static_cast<unsigned char>(n[i]);
+                            if(ch >= 'A' && ch <= 'Z') ch = static_cast<unsigned char>(ch + ('a' - 'A'));
+                            same = ch == static_cast<unsigned char>(lower[i]);
+                        }
+                        if(same) return idx;
+                    }
+                    return SIZE_MAX;
+                }
+                bool step_changed_tr(double last_step, double now_step) noexcept override
+                {
+                    if constexpr(defines::can_step_changed_tr<T>) return step_changed_tr_define(model_reserve_type<T>, m, last_step, now_step);
+                    else
+                        return true;
+                }
+                bool adapt_step(double& step) noexcept override
+                {
+                    if constexpr(defines::can_adapt_step<T>) return adapt_step_define(model_reserve_type<T>, m, step);
+                    else
+                        return true;
+                }
+                bool check_convergence() noexcept override
+                {
+                    if constexpr(defines::can_check_convergence<T>) return check_convergence_define(model_reserve_type<T>, m);
+                    else
+                        return true;
                 }
                 ::phy_engine::digital::need_operate_analog_node_t
                     update_digital_clk(::phy_engine::digital::digital_node_update_table& table, double tr_duration, digital_update_method_t method) noexcept override
@@ -656,8 +927,63 @@ namespace phy_engine
             ::std::vector<details::netlist_node_block> nodes{};
             ::phy_engine::model::node_t ground_node{};
             netlist() = default;
-            netlist(netlist const&) = delete;
-            netlist& operator=(netlist const&) = delete;
+            // netlist/netlist.h:182-329: deep copy.  Models are cloned chunk by chunk at the same (vec_pos, chunk_pos) positions,
+            // nodes likewise, and every pin of a copied model is attached to the copy of the node it was attached to.
+            netlist(netlist const& o) { copy_from(o); }
+            netlist& operator=(netlist const& o)
+            {
+                if(this != &o)
+                {
+                    models.clear();
+                    nodes.clear();
+                    ground_node.clear();
+                    copy_from(o);
+                }
+                return *this;
+            }
+            netlist(netlist&&) = delete;  // (addresses of models and nodes are what pins and callers hold)
+
+        private:
+            void copy_from(netlist const& o)
+            {
+                ::std::map<::phy_engine::model::node_t const*, ::phy_engine::model::node_t*> twin;
+                twin[&o.ground_node] = &ground_node;
+                ground_node.node_information = o.ground_node.node_information;
+                ground_node.num_of_analog_node = o.ground_node.num_of_analog_node;
+                nodes.reserve(o.nodes.size());
+                for(auto const& ob: o.nodes)
+                {
+                    auto& nb = nodes.emplace_back();
+                    for(auto const* p = ob.begin; p != ob.curr; ++p, ++nb.curr)
+                    {
+                        ::new(nb.curr)::phy_engine::model::node_t{*p};  // (node_t's copy keeps the state, not the pin set)
+                        nb.curr->num_of_analog_node = p->num_of_analog_node;
+                        twin[p] = nb.curr;
+                    }
+                }
+                models.reserve(o.models.size());
+                for(auto const& ob: o.models)
+                {
+                    auto& nb = models.emplace_back();
+                    nb.num_of_null_model = ob.num_of_null_model;
+                    for(auto const* p = ob.begin; p != ob.curr; ++p, ++nb.curr)
+                    {
+                        ::new(nb.curr)::phy_engine::model::model_base{*p};  // clone; its pins come back detached
+                        if(p->type != ::phy_engine::model::model_type::normal || !p->ptr) continue;
+                        auto const from = p->ptr->generate_pin_view();
+                        auto const to = nb.curr->ptr->generate_pin_view();
+                        for(::std::size_t i = 0; i < from.size && i < to.size; ++i)
+                        {
+                            auto const it = from.pins[i].nodes ? twin.find(from.pins[i].nodes) : twin.end();
+                            if(it == twin.end()) continue;  // unattached, or attached to a node of another netlist
+                            to.pins[i].nodes = it->second;
+                            it->second->pins.insert(to.pins + i);
+                        }
+                    }
+                }
+            }
+
+        public:
         };
 
         struct model_pos
@@ -788,8 +1114,8 @@ namespace phy_engine
         bool has_prepare{};
         ::std::size_t node_counter{};
         ::std::size_t branch_counter{};
-        ::std::vector<::phy_engine::model::node_t*> size_t_to_node_p{};
-        ::std::vector<::phy_engine::model::branch*> size_t_to_branch_p{};
+        ::fast_io::vector<::phy_engine::model::node_t*> size_t_to_node_p{};
+        ::fast_io::vector<::phy_engine::model::branch*> size_t_to_branch_p{};
         ::phy_engine::digital::digital_node_update_table digital_update_tables{};
         ::std::vector<::phy_engine::digital::need_operate_analog_node_t> digital_out{};
         ::std::vector<::phy_engine::model::model_base*> before_all_clk_digital_model{};
@@ -798,6 +1124,10 @@ namespace phy_engine
         double last_step{};
         ::std::string last_error{};
         pe_hip_run_stats last_stats{};
+        // circuit.h:100: the assembled system.  Here: after an analysis of a circuit of up to `mna_mirror_rows` rows, a host copy of
+        // the last system the device assembled (built-in models and host-stamped ones together), for inspection only.
+        ::phy_engine::MNA::MNA mna{};
+        ::std::size_t mna_mirror_rows{2048};
 
         circult() = default;
         circult(circult const&) = delete;
@@ -1016,6 +1346,7 @@ namespace phy_engine
             after_all_clk_digital_model.clear();
 
             tables_ next{};
+            ::std::vector<model_base*> next_overlay{};
             for(auto& blk: nl.models)
                 for(auto* c = blk.begin; c != blk.curr; ++c)
                 {
@@ -1037,12 +1368,40 @@ namespace phy_engine
                             after_all_clk_digital_model.push_back(c);
                         continue;  // event logic stays on the host
                     }
+                    // circuit.h:595-635 (every analysis branch): global TNOM reaches a model that exposes "tnom" and still has the
+                    // default 27 C; the environment temperature reaches every model (hook, or the "Temp" attribute fallback)
+                    if(env.norm_temperature != 27.0)
+                    {
+                        ::std::size_t const idx{c->ptr->find_attribute(u8"tnom")};
+                        if(idx != SIZE_MAX)
+                        {
+                            auto const cur = c->ptr->get_attribute(idx);
+                            if(!(cur.type == variant_type::d && ::std::abs(cur.d - 27.0) > 1e-12))
+                            {
+                                variant v{};
+                                v.d = env.norm_temperature;
+                                v.type = variant_type::d;
+                                (void)c->ptr->set_attribute(idx, v);
+                            }
+                        }
+                    }
+                    if(!c->ptr->load_temperature(env.temperature))
+                    {
+                        last_error = "load_temperature_define returned false";
+                        return false;
+                    }
                     gpu_table_rows rows{};
                     if(!c->ptr->has_gpu_table() || !c->ptr->gpu_table(rows))
                     {
+                        // no device table: a plug-in model with the reference's host hooks only -> host-stamp overlay
+                        if(c->ptr->has_host_stamp())
+                        {
+                            next_overlay.push_back(c);
+                            continue;
+                        }
                         auto const nm = c->ptr->get_model_name();
                         last_error = "model '" + ::std::string(reinterpret_cast<char const*>(nm.data()), nm.size()) +
-                                     "' has no gpu_table_define hook: the MI355X engine has no host stamping path";
+                                     "' has neither a gpu_table_define hook nor an iterate_*_define hook";
                         return false;
                     }
                     for(int r = 0; r < rows.count; ++r)
@@ -1084,6 +1443,7 @@ namespace phy_engine
                     return false;
                 }
             }
+            if(!prepare_overlay(::std::move(next_overlay), next)) return false;
             pe_hip_options o{};
             o.v_abstol = env.V_eps_max;
             o.v_reltol = env.V_epsr_max;
@@ -1143,7 +1503,11 @@ namespace phy_engine
             int const mode = at == analyze_type::OP ? PE_HIP_MODE_OP : (at == analyze_type::TROP ? PE_HIP_MODE_TROP : PE_HIP_MODE_DC);
             int const rc = node_counter + branch_counter == 0 ? PE_HIP_OK : pe_hip_analyze_dc(gpu_, mode, &last_stats);
             scatter();
+            mirror_mna();
             if(rc != PE_HIP_OK) return gpu_fail();
+            // circuit.h:965-975: the operating point is saved by the non-linear models once the solve has converged
+            for(auto* c: overlay_models_)
+                if(!c->ptr->save_op()) return overlay_hook_failed(c, "save_op_define");
             return true;
         }
 
@@ -1159,9 +1523,12 @@ namespace phy_engine
             table_ kind[PE_HIP_KIND_MAX + 1]{};
             ::std::vector<int> drv_node;
             ::std::vector<double> drv_volt;
+            ::std::vector<int> ov_rows, ov_cols, ov_rhs;  // host-stamp overlay cells (absolute MNA indices)
+            bool ov_nonlinear{};
             bool same_topology(tables_ const& o) const
             {
                 if(n_nodes != o.n_nodes || n_branches != o.n_branches || drv_node != o.drv_node) return false;
+                if(ov_rows != o.ov_rows || ov_cols != o.ov_cols || ov_rhs != o.ov_rhs || ov_nonlinear != o.ov_nonlinear) return false;
                 for(int k = 1; k <= PE_HIP_KIND_MAX; ++k)
                     if(kind[k].nodes != o.kind[k].nodes || kind[k].branch != o.kind[k].branch || kind[k].params.size() != o.kind[k].params.size()) return false;
                 return true;
@@ -1176,6 +1543,154 @@ namespace phy_engine
         {
             last_error = pe_hip_last_error(gpu_);
             return false;
+        }
+
+        // ---- host-stamp overlay (include/pe_hip.h: pe_hip_set_overlay) ---------------------------------------------------------
+        // Plug-in models without a device table keep the reference's contract: their iterate_*_define hooks stamp into an MNA.
+        // prepare() runs every stamp hook such a model has once to DISCOVER the cells it touches (the pattern only grows:
+        // mna_keep_pattern_ready, circuit.h:993-1003), registers those cells with the engine, and from then on the engine calls
+        // back once per Newton iteration: node voltages / branch currents of the current iterate are scattered into the netlist
+        // (the hooks read them through their pins, as in the reference), the hooks stamp, the values go to the device.
+        ::std::vector<::phy_engine::model::model_base*> overlay_models_{};
+        ::phy_engine::MNA::MNA overlay_mna_{};
+        ::std::vector<::std::pair<::std::size_t, ::std::size_t>> overlay_cells_{};  // (row, col), the order of the uploaded values
+        ::std::vector<::std::size_t> overlay_rhs_{};
+        bool overlay_failed_{};
+
+        bool overlay_stamp(int mode, double t) noexcept
+        {
+            overlay_mna_.r_open = env.r_open > 0.0 ? env.r_open : 1e12;
+            for(auto* c: overlay_models_)
+            {
+                bool ok{};
+                switch(mode)
+                {
+                    case PE_HIP_MODE_OP: ok = c->ptr->iterate_op(overlay_mna_); break;
+                    case PE_HIP_MODE_TR: ok = c->ptr->iterate_tr(overlay_mna_, t); break;
+                    case PE_HIP_MODE_TROP: ok = c->ptr->iterate_trop(overlay_mna_); break;
+                    default: ok = c->ptr->iterate_dc(overlay_mna_); break;
+                }
+                if(!ok) return false;
+            }
+            return true;
+        }
+        void scatter_from(double const* x) noexcept
+        {
+            for(auto* n: size_t_to_node_p) n->node_information.an.voltage = x[n->node_index];
+            nl.ground_node.node_information.an.voltage = {};
+            for(auto* b: size_t_to_branch_p) b->current = x[node_counter + b->index];
+        }
+        static int overlay_trampoline(void* user, int event, int mode, double t, double dt, double const* x, double* a_values, double* b_values) noexcept
+        {
+            auto& self = *static_cast<circult*>(user);
+            self.scatter_from(x);
+            if(event == PE_HIP_OVERLAY_STEP)
+            {
+                for(auto* c: self.overlay_models_)
+                    if(!c->ptr->step_changed_tr(self.last_step, dt)) return 1;
+                return 0;
+            }
+            self.overlay_mna_.clear_values_keep_pattern();
+            if(!self.overlay_stamp(mode, t)) return 1;
+            // a cell outside the registered pattern cannot be added mid-analysis: fail loudly (the next prepare() re-discovers)
+            ::std::size_t cells{};
+            for(auto const& row: self.overlay_mna_.A) cells += row.size();
+            if(cells != self.overlay_cells_.size() || self.overlay_mna_.Z.size() != self.overlay_rhs_.size())
+            {
+                self.overlay_failed_ = true;
+                return 2;
+            }
+            for(::std::size_t i = 0; i < self.overlay_cells_.size(); ++i)
+                a_values[i] = self.overlay_mna_.A[self.overlay_cells_[i].first][self.overlay_cells_[i].second].real();
+            for(::std::size_t i = 0; i < self.overlay_rhs_.size(); ++i) b_values[i] = self.overlay_mna_.Z[self.overlay_rhs_[i]].real();
+            return 0;
+        }
+        // init / prepare hooks (circuit.h:560-640), discovery stamp, registration with the engine
+        bool prepare_overlay(::std::vector<::phy_engine::model::model_base*> models, tables_& next) noexcept
+        {
+            bool const same_models = models == overlay_models_;
+            overlay_models_ = ::std::move(models);
+            if(overlay_models_.empty())
+            {
+                overlay_cells_.clear();
+                overlay_rhs_.clear();
+                return pe_hip_set_overlay(gpu_, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr) == PE_HIP_OK || gpu_fail();
+            }
+            bool nonlinear{};
+            for(auto* c: overlay_models_)
+            {
+                if(!c->has_init)
+                {
+                    if(!c->ptr->init_model()) return overlay_hook_failed(c, "init_define");
+                    c->has_init = true;
+                }
+                if(!c->ptr->prepare_for(static_cast<int>(at))) return overlay_hook_failed(c, "prepare_*_define");
+                nonlinear = nonlinear || c->ptr->get_device_type() == ::phy_engine::model::model_device_type::non_linear;
+            }
+            if(!same_models || overlay_failed_ || overlay_mna_.node_size != node_counter || overlay_mna_.branch_size != branch_counter)
+            {
+                overlay_mna_ = ::phy_engine::MNA::MNA{node_counter, branch_counter};
+                overlay_failed_ = false;
+            }
+            // discovery: every stamp the models can produce for this analysis (TR also needs the DC-like stamp of the first point)
+            int const modes[2] = {at == analyze_type::TR || at == analyze_type::TROP ? PE_HIP_MODE_TR : (at == analyze_type::OP ? PE_HIP_MODE_OP : PE_HIP_MODE_DC),
+                                  at == analyze_type::TROP ? PE_HIP_MODE_TROP : PE_HIP_MODE_DC};
+            for(int q = 1; q >= 0; --q)  // the analysis' own mode last: its values are the representative ones
+            {
+                overlay_mna_.clear_values_keep_pattern();
+                if(!overlay_stamp(modes[q], tr_duration)) return overlay_hook_failed(nullptr, "iterate_*_define");
+            }
+            overlay_cells_.clear();
+            overlay_rhs_.clear();
+            ::std::vector<double> rep;
+            for(::std::size_t r = 0; r < overlay_mna_.A.size(); ++r)
+                for(auto const& [col, v]: overlay_mna_.A[r])
+                {
+                    overlay_cells_.emplace_back(r, col);
+                    next.ov_rows.push_back(static_cast<int>(r));
+                    next.ov_cols.push_back(static_cast<int>(col));
+                    rep.push_back(::std::abs(v) > 0.0 ? ::std::abs(v) : 1.0);
+                }
+            for(auto const& [row, v]: overlay_mna_.Z)
+            {
+                overlay_rhs_.push_back(row);
+                next.ov_rhs.push_back(static_cast<int>(row));
+            }
+            next.ov_nonlinear = nonlinear;
+            if(pe_hip_set_overlay(gpu_, static_cast<int>(next.ov_rows.size()), next.ov_rows.data(), next.ov_cols.data(), rep.data(), static_cast<int>(next.ov_rhs.size()),
+                                  next.ov_rhs.data(), nonlinear ? 1 : 0, &circult::overlay_trampoline, this) != PE_HIP_OK)
+                return gpu_fail();
+            return true;
+        }
+        bool overlay_hook_failed(::phy_engine::model::model_base* c, char const* hook) noexcept
+        {
+            last_error = ::std::string("host-stamped model");
+            if(c)
+            {
+                auto const nm = c->ptr->get_model_name();
+                last_error += " '" + ::std::string(reinterpret_cast<char const*>(nm.data()), nm.size()) + "'";
+            }
+            last_error += ::std::string(": ") + hook + " returned false";
+            return false;
+        }
+        // host copy of the system the device assembled last (small circuits only; circuit.h:100 `mna`)
+        void mirror_mna() noexcept
+        {
+            ::std::size_t const rows = node_counter + branch_counter;
+            mna.clear();
+            mna.resize(node_counter, branch_counter);
+            if(!rows || rows > mna_mirror_rows || !gpu_ || !loaded_) return;
+            pe_hip_info info{};
+            if(pe_hip_get_info(gpu_, &info) != PE_HIP_OK) return;
+            int const nnz{info.nnz_a};
+            ::std::vector<int> rp(rows + 1), ci(static_cast<::std::size_t>(nnz));
+            ::std::vector<double> va(static_cast<::std::size_t>(nnz)), rhs(rows);
+            if(pe_hip_get_matrix(gpu_, 0, rp.data(), ci.data(), va.data(), rhs.data()) != PE_HIP_OK) return;
+            for(::std::size_t r = 0; r < rows; ++r)
+            {
+                for(int e = rp[r]; e < rp[r + 1]; ++e) mna.A[r][static_cast<::std::size_t>(ci[e])] = va[static_cast<::std::size_t>(e)];
+                if(rhs[r] != 0.0) mna.Z[r] = rhs[r];
+            }
         }
 
         // circuit.h:1521-1523
@@ -1213,6 +1728,7 @@ namespace phy_engine
             }
             int const rc = (n == 0 || node_counter + branch_counter == 0) ? PE_HIP_OK : pe_hip_analyze_tr(gpu_, dt, n, &last_stats);
             scatter();
+            mirror_mna();
             double t_now = tr_duration;
             long long steps = 0;
             if(node_counter + branch_counter != 0)

@@ -1,7 +1,7 @@
 // Config C2: VAC 10 V / 50 Hz -> full_bridge_rectifier -> 1 kOhm || 100 uF, g_min = 1e-12, through the
 // C++ plug-in API: v+(5 ms) and v+(30 ms) against the values the real reference produces (tests/golden/bridge_c2).
-// Also: a user model WITHOUT the gpu_table_define hook is accepted by add_model (it has iterate_dc_define) but
-// analyze() refuses it loudly -- there is no host stamping path.
+// Also: a user model WITHOUT the gpu_table_define hook (it only has the reference's iterate_dc_define) is stamped on the host and
+// added to the device-side system (host-stamp overlay, include/pe_hip.h pe_hip_set_overlay).
 #include <cmath>
 #include <cstdio>
 #include <numbers>
@@ -17,7 +17,15 @@ namespace user
         inline static constexpr ::fast_io::u8string_view identification_name{u8"HR"};
         ::phy_engine::model::pin pins[2]{{{u8"A"}}, {{u8"B"}}};
     };
-    inline bool iterate_dc_define(::phy_engine::model::model_reserve_type_t<host_only_resistor>, host_only_resistor const&, ::phy_engine::MNA::MNA&) noexcept { return true; }
+    inline bool iterate_dc_define(::phy_engine::model::model_reserve_type_t<host_only_resistor>, host_only_resistor const& m, ::phy_engine::MNA::MNA& mna) noexcept
+    {
+        auto const a{m.pins[0].nodes->node_index}, b{m.pins[1].nodes->node_index};
+        mna.G_ref(a, a) += 1e-3;
+        mna.G_ref(a, b) -= 1e-3;
+        mna.G_ref(b, a) -= 1e-3;
+        mna.G_ref(b, b) += 1e-3;
+        return true;
+    }
     inline ::phy_engine::model::pin_view generate_pin_view_define(::phy_engine::model::model_reserve_type_t<host_only_resistor>, host_only_resistor& m) noexcept { return {m.pins, 2}; }
 }  // namespace user
 
@@ -70,14 +78,27 @@ int main()
         std::fprintf(stderr, "bridge: v+(30ms)=%.12g\n", v30);
         return 4;
     }
-    // a host-only model is a valid plug-in for add_model, but the engine refuses to analyze it
+    // a model that only has the reference's host hooks (no gpu_table_define) runs through the host-stamp overlay: here a 1 kOhm
+    // "resistor" whose iterate_dc_define stamps its conductance, in series with a built-in 1 kOhm on 2 V -> 1 V at the tap
     circult c2{};
     c2.set_analyze_type(analyze_type::DC);
-    auto [hr, hp]{add_model(c2.get_netlist(), user::host_only_resistor{})};
-    auto& n1{create_node(c2.get_netlist())};
-    add_to_node(c2.get_netlist(), *hr, 0, n1);
-    add_to_node(c2.get_netlist(), *hr, 1, c2.get_netlist().ground_node);
-    if(c2.analyze()) return 5;
-    if(c2.last_error.find("gpu_table_define") == std::string::npos) return 6;
+    auto& nl2{c2.get_netlist()};
+    auto [hr, hp]{add_model(nl2, user::host_only_resistor{})};
+    auto [r2, r2p]{add_model(nl2, model::resistance{.r = 1000.0})};
+    auto [v2, v2p]{add_model(nl2, model::VDC{.V = 2.0})};
+    auto& top{create_node(nl2)};
+    auto& tap{create_node(nl2)};
+    add_to_node(nl2, *v2, 0, top);
+    add_to_node(nl2, *v2, 1, nl2.ground_node);
+    add_to_node(nl2, *r2, 0, top);
+    add_to_node(nl2, *r2, 1, tap);
+    add_to_node(nl2, *hr, 0, tap);
+    add_to_node(nl2, *hr, 1, nl2.ground_node);
+    if(!c2.analyze())
+    {
+        std::fprintf(stderr, "host-stamped resistor: %s\n", c2.last_error.c_str());
+        return 5;
+    }
+    if(std::abs(tap.node_information.an.voltage.real() - 1.0) > 1e-12) return 6;
     return 0;
 }
