@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- transient hot path on the synthetic 10k-node RC mesh (BASELINE.json metric).
 
-Workload (config C3/C5 of SURVEY.md 8d): M10k-NL = 100x100 RC mesh, R 1k +-5%, C 1p +-5%, 1249 clamp diodes,
-VAC 2 V / 100 MHz through 50 ohm, dt = 1e-10 s.  Every GPU holds `--batch` (default 1024: the whole C5 sweep on one
-GPU; weak scaling keeps 1024 per GPU) independent Monte-Carlo instances
-(seed = global instance index + 1) that share one symbolic analysis; a "step" is one transient time step of every
-instance on that GPU (companion update -> Newton{device eval, MNA gather, multifrontal LU, triangular solves,
-convergence test}).  Weak scaling: per-GPU work is fixed, no data-path collective; the only collective is the
-final reduction of per-node statistics (RCCL all-reduce), outside the timed region and reported as reduce_ms.
+Workload (config C5 of SURVEY.md 8d = BASELINE.json configs[4], the largest single-GPU configuration; at N = 1 the whole sweep
+sits on the one GPU): M10k-NL = 100x100 RC mesh, R 1k +-5%, C 1p +-5%, 1249 clamp diodes, VAC 2 V / 100 MHz through 50 ohm,
+dt = 1e-10 s, **1024 Monte-Carlo instances in total** (seed = global instance index + 1) sharing one symbolic analysis.
+`--gpus N` shards them in contiguous blocks of ceil(1024 / N) per rank (the chunk rule of the reference's only multi-GPU code,
+src/pe_synth_cuda_u64_cones.cu:1894-1904): STRONG scaling, no data-path collective; the only exchange is the final reduction
+of per-node statistics (two packed RCCL all-reduces of 160 KB each), outside the timed region and reported as reduce_ms.
+`--batch B` overrides the per-GPU instance count (then every rank holds B instances: weak scaling, reported as such).
+A "step" is one transient time step of every instance of a rank (companion update -> Newton{device eval, MNA gather,
+multifrontal LU, triangular solves, convergence test}).
 
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -44,23 +46,54 @@ def bytes_per_iteration(info):
 
 
 def node_statistics(x):
-    """Per-row {sum v, sum v^2, min, max} over the local instances: the payload of the final reduction."""
+    """Per-row {sum v, sum v^2, min, max} over instances (numpy restatement of pe_hip_sweep_statistics; tests only)."""
     return np.stack([x.sum(axis=0), (x * x).sum(axis=0), x.min(axis=0), x.max(axis=0)])
 
 
 def reduce_statistics(local, dist=None, device=None):
-    """All-reduce the packed statistics over ranks: SUM for rows 0-1, MIN for row 2, MAX for row 3."""
+    """The sweep's one exchange step: local = [4][rows] {sum, sum of squares, min, max}.  Packed as
+    [sum, sum2] -> one all-reduce(SUM) and [-min, max] -> one all-reduce(MAX)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     import torch
     t = torch.from_numpy(np.ascontiguousarray(local)).to(device or "cpu")
-    s = t[:2].contiguous()
-    mn = t[2].contiguous()
-    mx = t[3].contiguous()
-    dist.all_reduce(s, op=dist.ReduceOp.SUM)
-    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    return torch.cat([s, mn[None], mx[None]]).cpu().numpy()
+    sums = t[:2].contiguous()
+    ext = torch.stack([-t[2], t[3]]).contiguous()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    dist.all_reduce(ext, op=dist.ReduceOp.MAX)
+    return torch.cat([sums, -ext[:1], ext[1:]]).cpu().numpy()
+
+
+def shard(total, world, rank):
+    """Contiguous blocks of ceil(total / world) instances per rank (the last ranks may get fewer, or none)."""
+    chunk = -(-total // world)
+    lo = min(total, rank * chunk)
+    return lo, min(total, lo + chunk)
+
+
+def measured_hbm_ceiling(device_index):
+    """On-box achievable HBM bandwidth (report the fraction of the spec AND of the measured ceiling): a
+    device-to-device stream copy of 2 GiB through torch (plumbing), read + written bytes over HIP-event time."""
+    try:
+        import torch
+        dev = torch.device("cuda", device_index)
+        n = 1 << 28  # 2 GiB of float64
+        a = torch.empty(n, dtype=torch.float64, device=dev).fill_(1.0)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1) / 5
+        del a, b
+        torch.cuda.empty_cache()
+        return 2.0 * n * 8 / (ms * 1e-3) / 1e9
+    except Exception as e:  # (reported, never fatal: the ceiling is an extra)
+        return f"unavailable: {type(e).__name__}: {e}"
 
 
 def cpu_baseline(deck, dt, nonlinear, budget_steps):
@@ -149,12 +182,42 @@ def single_circuit_numbers(pe, W, dt, device):
     return out
 
 
+def other_config_numbers(pe, device):
+    """steps/s of config C2 (diode-bridge transient, a 4-row circuit: pure launch/latency figure) and samples/s of
+    config C4 (flash-ADC mixed signal through the C++ plug-in API: tests/cpp/adc_flash, when it has been built)."""
+    out = {}
+    try:
+        eng = pe.ffi.Engine(device=device)
+        eng.set_options(g_min=1e-12)
+        eng.load_deck(pe.deck.bridge_rectifier())
+        eng.reset()
+        eng.analyze_tr(1e-5, 100)
+        st = eng.analyze_tr(1e-5, 3900)
+        out["c2_bridge_steps_per_s"] = st["steps"] / (st["gpu_ms"] * 1e-3)
+        out["c2_bridge_newton_iters_per_s"] = st["newton_iters"] / (st["gpu_ms"] * 1e-3)
+        eng.close()
+    except Exception as e:
+        out["c2_error"] = str(e)
+    exe = os.path.join(ROOT, "tests", "cpp", "_build", "adc_flash")
+    if os.path.exists(exe):
+        try:
+            r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+            j = json.loads(r.stdout)
+            if "samples_per_s" in j:
+                out["c4_adc_samples_per_s"] = j["samples_per_s"]
+                out["c4_note"] = j.get("timing_note", "")
+        except Exception as e:
+            out["c4_error"] = str(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1024, help="Monte-Carlo instances per GPU (config C5: the 1024-instance sweep; weak scaling keeps it per GPU)")
+    ap.add_argument("--instances", type=int, default=1024, help="Monte-Carlo instances of the whole sweep (config C5), sharded over the GPUs")
+    ap.add_argument("--batch", type=int, default=0, help="override: instances PER GPU (weak scaling); 0 = shard --instances (strong scaling)")
     ap.add_argument("--mesh", type=int, default=100)
     ap.add_argument("--linear", action="store_true", help="VDC-driven linear variant (no diodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,8 +248,16 @@ def main():
     W = args.mesh
     nonlinear = not args.linear
     dt = 1e-10
-    B = args.batch
-    seeds = [rank * B + k + 1 for k in range(B)]
+    if args.batch > 0:
+        lo, hi = rank * args.batch, (rank + 1) * args.batch
+        total, scaling = world * args.batch, "weak"
+    else:
+        lo, hi = shard(args.instances, world, rank)
+        total, scaling = args.instances, "strong"
+    if hi <= lo:
+        raise SystemExit(f"rank {rank}: no instances to run ({total} instances over {world} ranks)")
+    B = hi - lo
+    seeds = [lo + k + 1 for k in range(B)]
     deck, r, c = pe.deck.rc_mesh_params(W, W, seeds, nonlinear)
     eng = pe.ffi.Engine(device=device_index)
     eng.set_options(g_min=0.0)
@@ -223,7 +294,7 @@ def main():
 
     # the one exchange step of the sweep: per-node statistics at t_end
     t1 = time.perf_counter()
-    stats = reduce_statistics(node_statistics(eng.solution()), dist, tdev)
+    stats = reduce_statistics(eng.sweep_statistics(), dist, tdev)
     reduce_ms = (time.perf_counter() - t1) * 1e3
 
     if rank == 0:
@@ -258,16 +329,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "newton_iters_per_s": iters_total / el,
             "newton_iters_per_step": iters_total / max(1.0, steps_total),
-            "config": {"workload": f"M10k{'-NL' if nonlinear else ''}: {W}x{W} RC mesh Monte-Carlo sweep, {B} instances/GPU, dt=1e-10, "
-                                   f"{'1249 diodes + VAC 2V 100MHz' if nonlinear else 'VDC 1V'}",
-                       "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_per_gpu": B,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "config": {"workload": f"M10k{'-NL' if nonlinear else ''}: {W}x{W} RC mesh Monte-Carlo sweep, {total} instances in total, dt=1e-10, "
+                                   f"{'1249 diodes + VAC 2V 100MHz' if nonlinear else 'VDC 1V'} (BASELINE.json configs[4]; configs[2] = one instance: single_circuit)",
+                       "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_total": total, "instances_rank0": B,
+                       "parallelism": f"contiguous blocks of ceil({total}/{world}) instances per GPU, no data-path collective, final statistics all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": kernel,
                          "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches, "bytes_per_launch": dom_bytes / dom_launches,
@@ -280,16 +351,23 @@ def main():
             "stats_checksum": float(np.sum(stats[0])),
             "engine": {k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
         }
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        ceiling = measured_hbm_ceiling(device_index) if world == 1 else None
+        if isinstance(ceiling, float):
+            line["roofline"]["measured_ceiling"] = {"GBps": ceiling, "frac_of_measured": achieved / ceiling,
+                                                    "how": "device-to-device stream copy of 2 GiB (read + write bytes / HIP-event time), this run"}
+        elif ceiling:
+            line["roofline"]["measured_ceiling"] = {"GBps": None, "how": ceiling}
+        # HBM bytes of the dominant kernel from the PMC counters: OFFLINE figure (rocprofv3 cannot profile the process that prints
+        # this line) -- two separate --pmc passes of this same command, corrected with the factors calibrated on this engine's
+        # access shapes (scripts/hbm_calib.hip); copied from the committed summary only when it was measured for this configuration
+        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W:
-                    # measured offline with rocprofv3 --pmc on this same command (profiles/README.md); bytes per launch
-                    if tj.get("kernel", "k_tr_steps").split("<")[0] != kernel.split("<")[0]:
-                        raise KeyError("traffic measured for another kernel")
+                if tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W and \
+                        tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
                     line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_note"] = tj.get("note", "")
+                    line["roofline"]["traffic_source"] = "offline: " + tj.get("note", "")
             except Exception:
                 pass
         if world == 1 and not args.no_single:
@@ -298,6 +376,7 @@ def main():
                 line["single_circuit"] = single_circuit_numbers(pe, W, dt, device_index)
             except Exception as e:
                 line["single_circuit"] = {"error": str(e)}
+            line["other_configs"] = other_config_numbers(pe, device_index)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)

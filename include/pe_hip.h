@@ -220,6 +220,11 @@ int pe_hip_get_solution_ac(pe_hip_engine* h, int first_instance, int count, doub
 int pe_hip_get_solution(pe_hip_engine* h, int first_instance, int count, double* x);
 int pe_hip_set_solution(pe_hip_engine* h, int first_instance, int count, const double* x);
 /* per-instance: status (pe_hip_status), accepted steps, Newton iterations, current time */
+/* The sweep's one exchange step: per-row statistics of the current solution over this engine's instances,
+ * computed on the device -- out[0][r] = sum_b x_b[r], out[1][r] = sum_b x_b[r]^2, out[2][r] = min_b, out[3][r] = max_b
+ * (out: [4][rows] doubles, host memory).  Ranks combine them with one SUM and one MAX all-reduce (min travels as -min). */
+int pe_hip_sweep_statistics(pe_hip_engine* h, double* out);
+
 int pe_hip_get_instance_state(pe_hip_engine* h, int first_instance, int count, int* status, long long* steps, long long* iters, double* t);
 /* iteration count of every step of instance 0 since the last reset (parity with the reference's Newton counts) */
 int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_out);

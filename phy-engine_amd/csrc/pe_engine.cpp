@@ -93,6 +93,8 @@ struct pe_hip_engine
     pe_hip_overlay_fn overlay_fn{};
     void* overlay_user{};
     std::vector<double> ov_x, ov_a, ov_b;  // staging of the callback
+    double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
+    size_t stats_doubles{};
     Pool circ_pool;  // topology, params, state
     Pool sym_pool;   // symbolic arrays + factor storage
     pe::Symbolic sym;
@@ -837,6 +839,8 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->sym_class = -1;
     h->fact_valid = false;
     h->circ_pool.release();
+    h->stats_scratch = nullptr;
+    h->stats_doubles = 0;
     h->sym_pool.release();
     if(h->ac.eng)
     {
@@ -1164,6 +1168,27 @@ int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_o
     *n_out = len;
     int const n = std::min({len, capacity, h->V.trace_cap});
     if(n > 0 && iters) HIPCHK(h, hipMemcpy(iters, h->V.trace, n * sizeof(int), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_sweep_statistics(pe_hip_engine* h, double* out)
+{
+    if(!h || !h->loaded || !out) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int const rows = h->hc.rows, B = h->hc.batch;
+    if(rows == 0) return PE_HIP_OK;
+    int const n_chunks = std::clamp(B / 32, 1, 64);  // enough workgroups to stream x at HBM rate, few enough for a cheap second pass
+    size_t const need = static_cast<size_t>(n_chunks + 1) * 4 * rows;
+    if(h->stats_doubles < need)  // scratch kept with the resident circuit (an allocation per call would cost more than the kernels)
+    {
+        HIPCHK(h, h->circ_pool.alloc(h->stats_scratch, need, false));
+        h->stats_doubles = need;
+    }
+    double* partial = h->stats_scratch;
+    double* dev_out = h->stats_scratch + static_cast<size_t>(n_chunks) * 4 * rows;
+    HIPCHK(h, pe::launch_sweep_statistics(h->stream, h->V, n_chunks, partial, dev_out));
+    HIPCHK(h, hipMemcpyAsync(out, dev_out, static_cast<size_t>(4) * rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return PE_HIP_OK;
 }
 

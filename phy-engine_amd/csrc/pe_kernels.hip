@@ -822,6 +822,63 @@ namespace pe
         return hipGetLastError();
     }
 
+    // ---- sweep statistics: x[batch][rows] -> {sum, sum of squares, min, max}[rows].  Thread = row (coalesced over rows), grid.y =
+    // chunks of instances; a second pass combines the chunks in order (no atomics: bitwise reproducible).
+    __global__ void __launch_bounds__(256) k_sweep_stats_partial(double const* __restrict__ x, int rows, int batch, int chunk_len, double* __restrict__ partial)
+    {
+        int const r = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+        if(r >= rows) return;
+        int const c = static_cast<int>(blockIdx.y), b0 = c * chunk_len, b1 = b0 + chunk_len < batch ? b0 + chunk_len : batch;
+        double s = 0.0, q = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+        double const* p = x + static_cast<long long>(b0) * rows + r;
+        int b = b0;
+        for(; b + 4 <= b1; b += 4, p += 4ll * rows)
+        {
+            double const v0 = p[0], v1 = p[rows], v2 = p[2ll * rows], v3 = p[3ll * rows];
+            s += v0; q += v0 * v0; mn = fmin(mn, v0); mx = fmax(mx, v0);
+            s += v1; q += v1 * v1; mn = fmin(mn, v1); mx = fmax(mx, v1);
+            s += v2; q += v2 * v2; mn = fmin(mn, v2); mx = fmax(mx, v2);
+            s += v3; q += v3 * v3; mn = fmin(mn, v3); mx = fmax(mx, v3);
+        }
+        for(; b < b1; ++b, p += rows)
+        {
+            double const v = *p;
+            s += v; q += v * v; mn = fmin(mn, v); mx = fmax(mx, v);
+        }
+        double* o = partial + static_cast<long long>(c) * 4 * rows + r;
+        o[0] = s;
+        o[rows] = q;
+        o[2ll * rows] = mn;
+        o[3ll * rows] = mx;
+    }
+    __global__ void __launch_bounds__(256) k_sweep_stats_final(double const* __restrict__ partial, int rows, int n_chunks, double* __restrict__ out)
+    {
+        int const r = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+        if(r >= rows) return;
+        double s = 0.0, q = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+        for(int c = 0; c < n_chunks; ++c)
+        {
+            double const* p = partial + static_cast<long long>(c) * 4 * rows + r;
+            s += p[0];
+            q += p[rows];
+            mn = fmin(mn, p[2ll * rows]);
+            mx = fmax(mx, p[3ll * rows]);
+        }
+        out[r] = s;
+        out[rows + r] = q;
+        out[2ll * rows + r] = mn;
+        out[3ll * rows + r] = mx;
+    }
+    hipError_t launch_sweep_statistics(hipStream_t st, DevView const& V, int n_chunks, double* partial, double* out)
+    {
+        if(V.rows <= 0 || V.batch <= 0) return hipSuccess;
+        int const chunk_len = (V.batch + n_chunks - 1) / n_chunks;
+        dim3 const grid((V.rows + 255) / 256, n_chunks);
+        hipLaunchKernelGGL(k_sweep_stats_partial, grid, dim3(256), 0, st, V.x, V.rows, V.batch, chunk_len, partial);
+        hipLaunchKernelGGL(k_sweep_stats_final, dim3(grid.x), dim3(256), 0, st, partial, V.rows, n_chunks, out);
+        return hipGetLastError();
+    }
+
     hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);

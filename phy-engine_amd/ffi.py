@@ -25,7 +25,7 @@ EXPORTS = [
     "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real",
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
-    "pe_hip_get_instance_state", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
+    "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
     "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",
 ]
 
@@ -88,6 +88,7 @@ def lib():
         l.pe_hip_analyze_tr.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(RunStats)]
         l.pe_hip_get_solution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         l.pe_hip_set_solution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        l.pe_hip_sweep_statistics.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         l.pe_hip_get_instance_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
                                                 C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         l.pe_hip_get_newton_trace.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -281,6 +282,12 @@ class Engine:
         x = np.empty((count, self.rows))
         self._chk(lib().pe_hip_get_solution(self._h, first, count, _dp(x)))
         return x
+
+    def sweep_statistics(self):
+        """[4][rows]: sum, sum of squares, min, max of the current solution over this engine's instances (computed on the device)."""
+        out = np.empty((4, self.rows))
+        self._chk(lib().pe_hip_sweep_statistics(self._h, _dp(out)))
+        return out
 
     def set_solution(self, x, first=0):
         x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1, self.rows)

@@ -48,6 +48,9 @@ for sd in range(2, 9):
     CASES[f"mesh32_lin_seed{sd}"] = (("rc_mesh", {"W": 32, "H": 32, "seed": sd, "nonlinear": False}), "TR", 1e-10, 100, 0.0, "100", False)
     CASES[f"mesh32_nl_seed{sd}"] = (("rc_mesh", {"W": 32, "H": 32, "seed": sd, "nonlinear": True}), "TR", 1e-10, 100, 0.0, "100", False)
 CASES["mesh100_lin_seed2"] = (("rc_mesh", {"W": 100, "H": 100, "seed": 2, "nonlinear": False}), "TR", 1e-10, 100, 0.0, "100", False)
+# config C5: exact per-instance parity of the M10k-NL sweep for seeds 1..8 (seed 1 = mesh100_nl)
+for sd in range(2, 9):
+    CASES[f"mesh100_nl_seed{sd}"] = (("rc_mesh", {"W": 100, "H": 100, "seed": sd, "nonlinear": True}), "TR", 1e-10, 100, 0.0, "10,100", False)
 
 
 # the reference's own model tests (DC) + transient variants of the same devices
@@ -139,6 +142,33 @@ def run_case(name):
     return name, meta["rows"], meta["fail_step"], meta.get("analyze_bit_equal")
 
 
+def sweep_statistics(name="mesh100_nl_stats32", W=100, seeds=range(1, 33), steps=10):
+    """Config C5: per-row {sum, sum of squares, min, max} of the solution after `steps` steps over the instances seed = 1..32
+    of the M10k-NL sweep, each run by the REAL reference -- the 32-instance CPU subset SURVEY.md 8(d) compares the sweep's
+    statistics with.  tests/golden/<name>.bin = float64 [4][rows]."""
+    import numpy as np
+
+    def one(sd):
+        d = deck.rc_mesh(W, W, sd, True)
+        with tempfile.TemporaryDirectory() as tmp:
+            dp = os.path.join(tmp, "m.deck")
+            d.write(dp)
+            out = os.path.join(tmp, "m")
+            subprocess.run([DRIVER, dp, "--analysis", "TR", "--gmin", "0.0", "--out", out, "--dt", repr(1e-10), "--steps", str(steps), "--snap", str(steps)], check=True)
+            meta = json.load(open(out + ".json"))
+            return np.fromfile(out + ".bin").reshape(-1, meta["rows"])[-1], meta["newton_iters"]
+
+    with cf.ThreadPoolExecutor(max_workers=8) as ex:
+        res = list(ex.map(one, seeds))
+    x = np.stack([r[0] for r in res])
+    stats = np.stack([x.sum(axis=0), (x * x).sum(axis=0), x.min(axis=0), x.max(axis=0)])
+    stats.tofile(os.path.join(GOLD, name + ".bin"))
+    json.dump({"rows": int(x.shape[1]), "seeds": list(seeds), "steps": steps, "dt": 1e-10, "mesh": W, "layout": "[sum, sum of squares, min, max][rows]",
+               "newton_iters_total": [int(sum(r[1])) for r in res],
+               "generator": "scripts/make_golden.py stats via oracle/_ref/ref_driver (real reference), one run per seed"}, open(os.path.join(GOLD, name + ".json"), "w"))
+    return name, x.shape
+
+
 # goldens that are the plain output of a reference-linked program (oracle/Makefile): name -> (binary, file)
 PROGRAMS = {"adc": ("ref_adc", "adc_c4.json"), "digital": ("ref_digital", "digital_blocks.json")}
 
@@ -152,7 +182,9 @@ if __name__ == "__main__":
         json.loads(out)
         open(os.path.join(GOLD, fn), "w").write(out)
         print((n, fn, len(out)), flush=True)
-    names = [n for n in names if n not in PROGRAMS]
+    if "stats" in names:
+        print(sweep_statistics(), flush=True)
+    names = [n for n in names if n not in PROGRAMS and n != "stats"]
     with cf.ThreadPoolExecutor(max_workers=6) as ex:
         for r in ex.map(run_case, names):
             print(r, flush=True)

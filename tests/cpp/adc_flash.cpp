@@ -3,6 +3,7 @@
 // digital_clk() x 2.  Prints one JSON document in the format of oracle/ref_adc.cpp (the real reference), which
 // tests/test_gpu_cpp_api.py compares bit-exactly (digital) and to 1e-12 (ladder voltages).  Also checks the expected bin
 // the way the reference test does (:339-367).
+#include <chrono>
 #include <cstdio>
 #include <vector>
 
@@ -115,6 +116,23 @@ int main()
         for(std::size_t i = 0; i < kLevels; ++i) std::printf("%s%d", i ? ", " : "", static_cast<int>(out_nodes[i]->node_information.dn.state));
         std::printf("]}%s\n", s < 6 ? "," : "");
     }
-    std::printf("]}\n");
+    // config C4 throughput: the same seven inputs again, 20 rounds, on the now resident circuit -- per sample one
+    // set_attribute + analyze() (DC on the device) + two digital ticks on the host; nothing is printed inside the timed loop
+    auto const t0{std::chrono::steady_clock::now()};
+    int timed = 0;
+    for(int round = 0; round < 20 && rc == 0; ++round)
+        for(int s = 0; s < 7; ++s, ++timed)
+        {
+            pe::model::variant v{};
+            v.d = samples[s];
+            v.type = pe::model::variant_type::d;
+            (void)vsrc->ptr->set_attribute(0, v);
+            if(!c.analyze()) rc = 11;
+            c.digital_clk();
+            c.digital_clk();
+        }
+    double const el{std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()};
+    std::printf("], \"samples_per_s\": %.6g, \"timing_note\": \"%d samples (7 inputs x 20 rounds) on the resident circuit: set_attribute + analyze() + 2 digital ticks each\"}\n",
+                timed / el, timed);
     return rc;
 }

@@ -227,6 +227,35 @@ namespace pe
         }
         return hipSuccess;
     }
+    hipError_t launch_sweep_statistics(hipStream_t, DevView const& V, int n_chunks, double* partial, double* out)
+    {
+        (void)partial;
+        // the chunked summation order of the device kernels (so that the emulation checks the same arithmetic)
+        int const chunk_len = (V.batch + n_chunks - 1) / n_chunks;
+        for(int r = 0; r < V.rows; ++r)
+        {
+            double s = 0.0, q = 0.0, mn = INFINITY, mx = -INFINITY;
+            for(int c = 0; c < n_chunks; ++c)
+            {
+                double cs = 0.0, cq = 0.0;
+                for(int b = c * chunk_len; b < V.batch && b < (c + 1) * chunk_len; ++b)
+                {
+                    double const v = V.x[static_cast<long long>(b) * V.rows + r];
+                    cs += v;
+                    cq += v * v;
+                    mn = std::fmin(mn, v);
+                    mx = std::fmax(mx, v);
+                }
+                s += cs;
+                q += cq;
+            }
+            out[r] = s;
+            out[V.rows + r] = q;
+            out[2ll * V.rows + r] = mn;
+            out[3ll * V.rows + r] = mx;
+        }
+        return hipSuccess;
+    }
     hipError_t launch_factor_solve(hipStream_t, DevView const& V, bool do_factor)
     {
         std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);

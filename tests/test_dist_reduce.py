@@ -14,9 +14,19 @@ import bench
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 rng = np.random.default_rng(7)
-full = rng.standard_normal((6, 37))                       # 6 instances, 37 rows
-shard = full[rank * 3:(rank + 1) * 3]                     # contiguous instance blocks per rank
-out = bench.reduce_statistics(bench.node_statistics(shard), dist, torch.device("cpu"))
+full = rng.standard_normal((7, 37))                       # 7 instances (ragged: 4 + 3), 37 rows
+lo, hi = bench.shard(len(full), world, rank)              # contiguous blocks of ceil(7 / 2) instances per rank (bench.py --gpus N)
+assert (lo, hi) == ((0, 4) if rank == 0 else (4, 7))
+# [sum, sum2] -> one all-reduce(SUM); [-min, max] -> one all-reduce(MAX): two packed collectives in all
+calls = []
+real = dist.all_reduce
+def counted(t, op=dist.ReduceOp.SUM, **kw):
+    calls.append(op)
+    return real(t, op=op, **kw)
+dist.all_reduce = counted
+out = bench.reduce_statistics(bench.node_statistics(full[lo:hi]), dist, torch.device("cpu"))
+dist.all_reduce = real
+assert calls == [dist.ReduceOp.SUM, dist.ReduceOp.MAX], calls
 ref = bench.node_statistics(full)
 assert np.allclose(out, ref, rtol=0, atol=1e-12), (out - ref)
 dist.destroy_process_group()

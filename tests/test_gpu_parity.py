@@ -4,6 +4,8 @@
   (3) size-independent properties at BASELINE.json's full size.
 Tolerances (fp64): linear circuits abs 1e-9 + rel 1e-7; non-linear abs 1e-6 + rel 1e-5 (the Newton stop rule is
 1e-3 relative) -- in practice the iterates agree to ~1e-9 and the Newton counts are identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -666,3 +668,56 @@ def test_checkpoint_and_ac_in_split_schedule(monkeypatch):
     finally:
         e1.close()
         e2.close()
+
+
+def test_c5_sweep_1024_instances_parity_and_statistics():
+    """Config C5 AT SIZE (BASELINE.json configs[4]): the 1024-instance Monte-Carlo sweep of the M10k-NL mesh, seeds
+    1..1024, as ONE batch on the GPU -- the very workload bench.py times.
+      (i)   exact per-instance parity: instances seed = 1..8 against eight runs of the real reference at steps 10 and 100
+            (tests/golden/mesh100_nl{,_seed2..8}), NL tolerance (Newton's stop rule is 1e-3 relative);
+      (ii)  per-node {sum, sum of squares, min, max} over the instances seed = 1..32 after 10 steps against the same statistics of
+            32 reference runs (tests/golden/mesh100_nl_stats32: the 32-instance CPU subset of SURVEY.md 8d);
+      (iii) the device-side statistics kernel over all 1024 instances (pe_hip_sweep_statistics, the payload of the sweep's one
+            all-reduce) against numpy on the downloaded solutions, and the full sweep's mean against the subset's within sampling error."""
+    import json
+    B = 1024
+    seeds = list(range(1, B + 1))
+    deck, r, c = pe.deck.rc_mesh_params(100, 100, seeds, True)
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0)
+        e.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
+        e.reset()
+        st = e.analyze_tr(1e-10, 10)
+        assert st["n_failed"] == 0 and st["steps"] == 10 * B
+        x10 = e.solution(0, 32)
+        stats_dev = e.sweep_statistics()
+        x_all = e.solution()
+        # (iii) device kernel == numpy on the same data (different summation order only)
+        ref_all = np.stack([x_all.sum(axis=0), (x_all * x_all).sum(axis=0), x_all.min(axis=0), x_all.max(axis=0)])
+        assert np.max(np.abs(stats_dev[2:] - ref_all[2:])) == 0.0
+        assert max_err(stats_dev[:2], ref_all[:2], 1e-9, 1e-12) <= 1.0
+        # (ii) the 32-instance subset against 32 reference runs
+        meta = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mesh100_nl_stats32.json")))
+        gs = np.fromfile(os.path.join(os.path.dirname(__file__), "golden", "mesh100_nl_stats32.bin")).reshape(4, -1)
+        assert meta["seeds"] == list(range(1, 33)) and meta["steps"] == 10 and gs.shape[1] == e.rows
+        mine = np.stack([x10.sum(axis=0), (x10 * x10).sum(axis=0), x10.min(axis=0), x10.max(axis=0)])
+        assert max_err(mine[0], gs[0], 32 * NL[0], NL[1]) <= 1.0
+        assert max_err(mine[1], gs[1], 32 * NL[0], 2 * NL[1]) <= 1.0
+        assert max_err(mine[2:], gs[2:], *NL) <= 1.0
+        # the whole sweep's mean lies within sampling error of the subset's mean (6 standard errors of the 32-sample mean)
+        mean32 = gs[0] / 32.0
+        var32 = np.maximum(gs[1] / 32.0 - mean32 * mean32, 0.0)
+        mean_all = stats_dev[0] / B
+        assert np.mean(np.abs(mean_all - mean32) <= 6.0 * np.sqrt(var32 / 32.0) + 1e-6) > 0.99
+        # (i) seeds 1..8 at step 10, then at step 100
+        golds = [golden("mesh100_nl" if sd == 1 else f"mesh100_nl_seed{sd}") for sd in range(1, 9)]
+        for k, (gm, gx, _) in enumerate(golds):
+            assert max_err(x10[k], gx[gm["snap_steps"].index(10)], *NL) <= 1.0, f"seed {k + 1} at step 10"
+        st = e.analyze_tr(1e-10, 90)
+        assert st["n_failed"] == 0
+        x100 = e.solution(0, 8)
+        for k, (gm, gx, _) in enumerate(golds):
+            assert max_err(x100[k], gx[gm["snap_steps"].index(100)], *NL) <= 1.0, f"seed {k + 1} at step 100"
+    finally:
+        e.close()
