@@ -36,7 +36,9 @@ enum pe_hip_status
     PE_HIP_ERR_NO_DEVICE = -2, /* no HIP device, or the HIP runtime failed */
     PE_HIP_ERR_SINGULAR = -3,  /* zero / non-finite pivot (reference: factorizationIsOk()==false, circuit.h:1517) */
     PE_HIP_ERR_NO_CONVERGENCE = -4, /* Newton exhausted max_iter (reference: solve() returns false, circuit.h:984) */
-    PE_HIP_ERR_INTERNAL = -5
+    PE_HIP_ERR_INTERNAL = -5,
+    PE_HIP_ERR_INACCURATE = -6 /* the static-pivot LU left a residual ||Ax - b|| above tolerance that refinement and re-matching could not
+                                  repair (the reference pivots partially, Eigen/src/SparseLU/SparseLU.h:464-469); the step is rolled back */
 };
 
 /* device kinds of the resident path; parameter columns per device in `params` */
@@ -110,6 +112,9 @@ typedef struct pe_hip_options
     int max_newton; /* 0 -> 64 */
     int refactor_every_solve; /* 1 (default): factor on every solve_once like the reference; 0: reuse the factors of a linear circuit while dt is unchanged */
     double r_open; /* contact resistance of an open switch (environment.h r_open; <= 0 -> 1e12, circuit.h:1012) */
+    double residual_tol; /* safety net of the static-pivot LU: after every linear solve eta = ||Ax - b||_inf / (||A||_inf ||x||_inf + ||b||_inf)
+                            is checked per instance; above this (0 -> 1e-10, < 0 disables the check) the solve is refined with the same
+                            factors' order, then re-matched on that instance's values, else PE_HIP_ERR_INACCURATE */
 } pe_hip_options;
 
 /* mirrors cuda_sparse_lu::timings (cuda_sparse_lu.h:27-34) */
@@ -220,6 +225,15 @@ int pe_hip_get_solution_ac(pe_hip_engine* h, int first_instance, int count, doub
 int pe_hip_get_solution(pe_hip_engine* h, int first_instance, int count, double* x);
 int pe_hip_set_solution(pe_hip_engine* h, int first_instance, int count, const double* x);
 /* per-instance: status (pe_hip_status), accepted steps, Newton iterations, current time */
+/* Diagnostics of the residual safety net (pe_hip_options.residual_tol): solves repaired by iterative refinement, symbolic
+ * re-analyses on a failing instance's own values, and whether the engine has left the resident kernel for the host-driven
+ * (refining) schedule.  Any pointer may be NULL. */
+int pe_hip_get_safety_net_counters(pe_hip_engine* h, long long* refined, long long* rematched, int* careful);
+
+/* On-box achievable HBM bandwidth (SURVEY.md 8d "measure the achievable ceiling on the box with a device-to-device stream
+ * kernel"): copies `bytes` (two temporary buffers of that size) `reps` times; *gbps = (read + written bytes) / HIP-event time. */
+int pe_hip_measure_hbm_ceiling(pe_hip_engine* h, size_t bytes, int reps, double* gbps);
+
 /* The sweep's one exchange step: per-row statistics of the current solution over this engine's instances,
  * computed on the device -- out[0][r] = sum_b x_b[r], out[1][r] = sum_b x_b[r]^2, out[2][r] = min_b, out[3][r] = max_b
  * (out: [4][rows] doubles, host memory).  Ranks combine them with one SUM and one MAX all-reduce (min travels as -min). */

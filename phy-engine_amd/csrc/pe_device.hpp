@@ -132,5 +132,12 @@ namespace pe
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;
         int max_newton;
+        // ---- residual safety net of the static-pivot LU (pe_front.hpp residual_norms): CSR of A in ORIGINAL row / column order
+        // (shared), slot_e[slot] = index of that entry in aval (front-assembly order; null = identity), per-instance buffers
+        int const *csr_rp, *csr_ci, *slot_e;
+        double* xsave;    // [.][rows]  solution being refined
+        double* rres;     // [.][rows]  residual b - A x (right-hand side of the correction solve)
+        double* eta_acc;  // [.][4]     max |r_i|, max_i sum_j |a_ij|, max |x_i|, max |b_i| of the last solve (split schedule: atomic max)
+        double residual_tol;  // <= 0: check disabled
     };
 }  // namespace pe

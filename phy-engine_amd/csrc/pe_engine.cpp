@@ -93,6 +93,8 @@ struct pe_hip_engine
     pe_hip_overlay_fn overlay_fn{};
     void* overlay_user{};
     std::vector<double> ov_x, ov_a, ov_b;  // staging of the callback
+    bool careful{};               // residual safety net tripped on the resident kernel: stay on the host-driven (refining) schedule
+    long long n_refined{}, n_rematched{};  // solves repaired by refinement / symbolic re-analyses on an instance's own values (diagnostics)
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
     size_t stats_doubles{};
     Pool circ_pool;  // topology, params, state
@@ -165,6 +167,7 @@ namespace
         if(v && *v == '1') return true;
         if(v && *v == '0') return false;
         if(h->overlay_fn && (h->hc.n_ov_a || h->hc.n_ov_b)) return true;  // host-stamped models: the host drives the Newton loop
+        if(h->careful) return true;  // an inaccurate solve was detected: the host-driven loop refines / re-matches
         return h->V.n_parts > 1 || h->hc.rows >= 3000;
     }
 
@@ -201,6 +204,7 @@ namespace
         V.max_newton = o.max_newton > 0 ? o.max_newton : 64;
         V.keep_l21 = (o.refactor_every_solve || V.nonlinear) ? 0 : 1;  // only a linear circuit reuses its factors (separate forward pass over L21)
         V.r_open = r_open_of(h);
+        V.residual_tol = o.residual_tol < 0.0 ? 0.0 : (o.residual_tol > 0.0 ? o.residual_tol : 1e-10);
     }
 
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
@@ -392,7 +396,12 @@ namespace
         std::vector<double> av;
         if(!h->sym_values_override.empty()) av = h->sym_values_override;
         else
+        {
             pe::estimate_values(h->hc, tr, dt, h->opt.g_min, r_open_of(h), av);
+            // test knob: a pivot matching that cannot see magnitudes (every structural entry weighs 1) -- the deliberately bad
+            // static order the residual safety net is tested against; a re-match on an instance's own values is not affected
+            if(char const* k = std::getenv("PHY_ENGINE_HIP_TEST_BLIND_MATCH"); k && *k == '1') std::fill(av.begin(), av.end(), 1.0);
+        }
         pe::SymbolicOptions so{};
         {
             int const rc = analyze_fitting(h, h->hc.batch, h->hc.rows, h->hc.rows, h->hc.rp.data(), h->hc.ci.data(), av.data(), h->sym, so);
@@ -458,6 +467,9 @@ namespace
             HIPCHK(h, h->sym_pool.upload(h->V.a_ptr, ptr2));
             HIPCHK(h, h->sym_pool.upload(h->V.a_src, src2));
             h->V.asm_slot = nullptr;  // identity (pe_front.hpp front_factor); the solve_csr_real seam keeps CSR order + the map
+            std::vector<int> slot_e(nnz, 0);  // CSR slot -> position in aval (residual check walks A row by row in original order)
+            for(size_t e = 0; e < nnz; ++e) slot_e[S.asm_slot[e]] = static_cast<int>(e);
+            HIPCHK(h, h->sym_pool.upload(h->V.slot_e, slot_e));
         }
         h->sym_class = cls;
         h->fact_valid = false;
@@ -493,7 +505,9 @@ namespace
         }
         if(nfail)
         {
-            h->err = (first == PE_HIP_ERR_SINGULAR ? "singular matrix (zero / non-finite pivot)" : "Newton iteration did not converge");
+            h->err = first == PE_HIP_ERR_SINGULAR     ? "singular matrix (zero / non-finite pivot)"
+                     : first == PE_HIP_ERR_INACCURATE ? "linear solve left a residual above residual_tol (static pivot order unsuitable for these values)"
+                                                      : "Newton iteration did not converge";
             return first;
         }
         return PE_HIP_OK;
@@ -563,6 +577,61 @@ namespace
         return PE_HIP_OK;
     }
 
+    // Residual safety net on the host-driven schedule.  The iteration just launched left the four norms of every active instance's
+    // solve in eta_acc.  Instances above the tolerance get up to two rounds of iterative refinement (launch_m2_refine: active =
+    // exactly those); their flags are then the Newton / finiteness bits of the corrected x.  What refinement cannot repair leaves
+    // the iteration as PE_HIP_ERR_INACCURATE (the caller re-matches on that instance's values and retries the step).
+    int m2_check_residuals(pe_hip_engine* h, M2State& S, std::vector<int>& result, int& n_active)
+    {
+        int const B = h->hc.batch;
+        std::vector<double> eta(static_cast<size_t>(B) * 4);
+        auto pull_eta = [&]() -> int
+        {
+            HIPCHK(h, hipMemcpy(eta.data(), h->V.eta_acc, eta.size() * sizeof(double), hipMemcpyDeviceToHost));
+            return PE_HIP_OK;
+        };
+        auto bad = [&](int b)
+        {
+            double const* n = &eta[4 * static_cast<size_t>(b)];
+            double const den = n[1] * n[2] + n[3];
+            double const e = den > 0.0 ? n[0] / den : (n[0] > 0.0 ? INFINITY : 0.0);
+            return !(e <= h->V.residual_tol);
+        };
+        if(int const rc = pull_eta(); rc != PE_HIP_OK) return rc;
+        std::vector<int> todo;
+        for(int b = 0; b < B; ++b)
+            if(S.active[b] && !(S.flags[b] & 5) && bad(b)) todo.push_back(b);
+        if(todo.empty()) return PE_HIP_OK;
+        std::vector<int> mask(B);
+        for(int round = 0; round < 2 && !todo.empty(); ++round)
+        {
+            std::fill(mask.begin(), mask.end(), 0);
+            for(int b: todo) mask[b] = 1;
+            HIPCHK(h, hipMemcpyAsync(h->V.active, mask.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, pe::launch_m2_refine(h->stream, h->V));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if(int const rc = pull_eta(); rc != PE_HIP_OK) return rc;
+            std::vector<int> fl(B);
+            HIPCHK(h, hipMemcpy(fl.data(), h->V.flags, B * sizeof(int), hipMemcpyDeviceToHost));
+            std::vector<int> still;
+            for(int b: todo)
+            {
+                S.flags[b] = fl[b];
+                if((fl[b] & 5) == 0 && bad(b)) still.push_back(b);
+                else
+                    ++h->n_refined;
+            }
+            todo.swap(still);
+        }
+        for(int b: todo)
+        {
+            result[b] = PE_HIP_ERR_INACCURATE;
+            S.active[b] = 0;
+            --n_active;
+        }
+        return PE_HIP_OK;
+    }
+
     // one solve point of every instance whose status is OK; result[b] = iterations (> 0) or a negative status
     int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, bool do_factor, std::vector<int>& result, int& launches)
     {
@@ -592,6 +661,8 @@ namespace
                     ++h->dominant_launches;
                 }
             }
+            if(h->V.residual_tol > 0.0)
+                if(int const rrc = m2_check_residuals(h, S, result, n_active); rrc != PE_HIP_OK) return rrc;
             for(int b = 0; b < B; ++b)
             {
                 if(!S.active[b]) continue;
@@ -614,7 +685,9 @@ namespace
         return PE_HIP_OK;
     }
 
-    int run_m2_tr(pe_hip_engine* h, double dt, int nsteps, int& launches)
+    // `only` != null: a retry of exactly those instances after a rolled-back step -- the companion update of that step has already
+    // been applied (update_tr_step precedes the failing solve, circuit.h:246-248), so the first step of the retry skips it
+    int run_m2_tr(pe_hip_engine* h, double dt, int nsteps, int& launches, std::vector<int> const* only = nullptr)
     {
         M2State S;
         int rc = m2_pull(h, S);
@@ -627,14 +700,17 @@ namespace
             int alive = 0;
             for(int b = 0; b < B; ++b)
             {
-                S.active[b] = S.status[b] == PE_HIP_OK ? 1 : 0;
+                S.active[b] = (S.status[b] == PE_HIP_OK && (!only || (*only)[b])) ? 1 : 0;
                 alive += S.active[b];
             }
             if(!alive) break;
-            if(has_overlay(h))
+            if(only)  // (a retry of some instances: the others must not be touched by m2_point either)
+                for(int b = 0; b < B; ++b)
+                    if(!(*only)[b] && S.status[b] == PE_HIP_OK) S.status[b] = -1000;
+            if(has_overlay(h) && !(only && s == 0))
                 if(int const orc = overlay_call(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt); orc != PE_HIP_OK) return orc;
             HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
+            if(!(only && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
             double t_prev = 0.0;
             for(int b = 0; b < B; ++b)
@@ -666,15 +742,20 @@ namespace
                 }
             }
         }
+        for(int b = 0; b < B; ++b)
+            if(S.status[b] == -1000) S.status[b] = PE_HIP_OK;
         return m2_push(h, S, dt, true);
     }
 
-    int run_m2_dc(pe_hip_engine* h, int mode, int& launches)
+    int run_m2_dc(pe_hip_engine* h, int mode, int& launches, std::vector<int> const* only = nullptr)
     {
         M2State S;
         int rc = m2_pull(h, S);
         if(rc != PE_HIP_OK) return rc;
         int const B = h->hc.batch;
+        if(only)
+            for(int b = 0; b < B; ++b)
+                if(!(*only)[b] && S.status[b] == PE_HIP_OK) S.status[b] = -1000;
         std::vector<double> ls(B);
         HIPCHK(h, hipMemcpy(ls.data(), h->V.last_step, B * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<int> res;
@@ -688,7 +769,58 @@ namespace
             else
                 S.iters[b] += res[b];
         }
+        for(int b = 0; b < B; ++b)
+            if(S.status[b] == -1000) S.status[b] = PE_HIP_OK;
         return m2_push(h, S, 0.0, false);
+    }
+
+    // Residual safety net, last resort: instances whose solve stayed inaccurate (status PE_HIP_ERR_INACCURATE, step rolled back).
+    // First time: leave the resident kernel for the host-driven schedule, which refines.  After that: a new static pivot order
+    // from the values of the first failing instance (the order of load time came from instance 0 at the first dt).  Returns the
+    // instances to retry (status cleared) grouped by the steps they still owe, or an empty list when nothing more can be done.
+    int prepare_inaccurate_retry(pe_hip_engine* h, bool tr, double dt, int attempt, std::vector<long long> const& steps0, int nsteps,
+                                 std::vector<std::pair<int, std::vector<int>>>& groups)
+    {
+        groups.clear();
+        int const B = h->hc.batch;
+        std::vector<int> status(B);
+        std::vector<long long> s1(B);
+        HIPCHK(h, hipMemcpy(status.data(), h->V.status, B * sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpy(s1.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
+        std::vector<int> failed;
+        for(int b = 0; b < B; ++b)
+            if(status[b] == PE_HIP_ERR_INACCURATE) failed.push_back(b);
+        if(failed.empty() || attempt >= 2) return PE_HIP_OK;
+        if(attempt == 0 && !h->careful) h->careful = true;
+        else
+        {
+            // re-match on the failing instance's own assembled values (device order = front-assembly order -> CSR slots)
+            int const b = failed[0];
+            size_t const nnz = h->hc.ci.size();
+            std::vector<double> tmp(nnz);
+            HIPCHK(h, hipMemcpy(tmp.data(), h->V.aval + static_cast<size_t>(b) * nnz, nnz * sizeof(double), hipMemcpyDeviceToHost));
+            h->sym_values_override.assign(nnz, 0.0);
+            for(size_t e = 0; e < nnz; ++e) h->sym_values_override[h->sym.asm_slot[e]] = std::fabs(tmp[e]);
+            h->sym_class = -1;
+            int const rc = ensure_symbolic(h, tr, dt);
+            h->sym_values_override.clear();
+            if(rc != PE_HIP_OK) return rc;
+            ++h->n_rematched;
+        }
+        for(int b: failed) status[b] = PE_HIP_OK;
+        HIPCHK(h, hipMemcpy(h->V.status, status.data(), B * sizeof(int), hipMemcpyHostToDevice));
+        for(int b: failed)
+        {
+            int const owe = tr ? nsteps - static_cast<int>(s1[b] - steps0[b]) : 1;
+            auto it = std::find_if(groups.begin(), groups.end(), [&](auto const& g) { return g.first == owe; });
+            if(it == groups.end())
+            {
+                groups.emplace_back(owe, std::vector<int>(B, 0));
+                it = groups.end() - 1;
+            }
+            it->second[b] = 1;
+        }
+        return PE_HIP_OK;
     }
 }  // namespace
 
@@ -932,6 +1064,13 @@ int finish_load(pe_hip_engine* h)
     HIPCHK(h, P.alloc(V.prof, B * pe::PE_PROF));
     HIPCHK(h, P.alloc(V.active, B));
     HIPCHK(h, P.alloc(V.flags, B));
+    // residual safety net: CSR of A in original order (shared) + per-instance refinement buffers
+    HIPCHK(h, P.upload(V.csr_rp, hc.rp));
+    HIPCHK(h, P.upload(V.csr_ci, hc.ci));
+    HIPCHK(h, P.alloc(V.xsave, B * hc.rows));
+    HIPCHK(h, P.alloc(V.rres, B * hc.rows));
+    HIPCHK(h, P.alloc(V.eta_acc, B * 4));
+    V.slot_e = nullptr;  // (set with the symbolic analysis: aval lives in front-assembly order)
     // static part of dv
     {
         std::vector<double> dv(B * hc.dv_len, 0.0);
@@ -1072,6 +1211,20 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
             h->fact_dt = dt;
         }
     }
+    if(h->V.residual_tol > 0.0)
+        for(int attempt = 0; attempt < 2; ++attempt)
+        {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            std::vector<std::pair<int, std::vector<int>>> groups;
+            rc = prepare_inaccurate_retry(h, true, dt, attempt, s0, nsteps, groups);
+            if(rc != PE_HIP_OK) return rc;
+            if(groups.empty()) break;
+            for(auto const& g: groups)
+            {
+                rc = run_m2_tr(h, dt, g.first, launches, &g.second);
+                if(rc != PE_HIP_OK) return rc;
+            }
+        }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -1114,6 +1267,21 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     }
     else
         HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode));
+    if(h->V.residual_tol > 0.0)
+        for(int attempt = 0; attempt < 2; ++attempt)
+        {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            std::vector<std::pair<int, std::vector<int>>> groups;
+            rc = prepare_inaccurate_retry(h, false, 0.0, attempt, s0, 1, groups);
+            if(rc != PE_HIP_OK) return rc;
+            if(groups.empty()) break;
+            int launches = 0;
+            for(auto const& g: groups)
+            {
+                rc = run_m2_dc(h, mode, launches, &g.second);
+                if(rc != PE_HIP_OK) return rc;
+            }
+        }
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0.f;
@@ -1168,6 +1336,35 @@ int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_o
     *n_out = len;
     int const n = std::min({len, capacity, h->V.trace_cap});
     if(n > 0 && iters) HIPCHK(h, hipMemcpy(iters, h->V.trace, n * sizeof(int), hipMemcpyDeviceToHost));
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_safety_net_counters(pe_hip_engine* h, long long* refined, long long* rematched, int* careful)
+{
+    if(!h) return PE_HIP_ERR_ARG;
+    if(refined) *refined = h->n_refined;
+    if(rematched) *rematched = h->n_rematched;
+    if(careful) *careful = h->careful ? 1 : 0;
+    return PE_HIP_OK;
+}
+
+int pe_hip_measure_hbm_ceiling(pe_hip_engine* h, size_t bytes, int reps, double* gbps)
+{
+    if(!h || !gbps || bytes < 16 || reps < 1) return PE_HIP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    bytes &= ~static_cast<size_t>(15);
+    Pool tmp;
+    char *a{}, *b{};
+    HIPCHK(h, tmp.alloc(a, bytes));
+    HIPCHK(h, tmp.alloc(b, bytes));
+    HIPCHK(h, pe::launch_stream_copy(h->stream, a, b, bytes));  // warm-up (first touch)
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    for(int r = 0; r < reps; ++r) HIPCHK(h, pe::launch_stream_copy(h->stream, a, b, bytes));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *gbps = ms > 0.f ? 2.0 * static_cast<double>(bytes) * reps / (static_cast<double>(ms) * 1e-3) / 1e9 : 0.0;
     return PE_HIP_OK;
 }
 

@@ -44,7 +44,8 @@ namespace pe
     {
         ST_OK = 0,
         ST_SINGULAR = -3,
-        ST_NO_CONVERGENCE = -4
+        ST_NO_CONVERGENCE = -4,
+        ST_INACCURATE = -6
     };
 
     PE_DEV double limexp(double x)
@@ -1248,6 +1249,48 @@ namespace pe
         tm.sync();
     }
 
+    // ------------------------------------------------------------------------------------------------
+    // Residual safety net of the static-pivot LU (the reference pivots partially: Eigen SparseLU, diagonal threshold 1.0).
+    // After a linear solve: r = b - A x row by row on the assembled values (A in original order through slot_e), and the four
+    // maxima of the normwise backward error  eta = ||r||_inf / (||A||_inf ||x||_inf + ||b||_inf).  A thread covers rows
+    // tid, tid + size, ..; out4 = this thread's partial {max |r_i|, max_i sum_j |a_ij|, max |x_i|, max |b_i|}; rres (may be
+    // null) receives r.  Non-finite values count as +inf.
+    // ------------------------------------------------------------------------------------------------
+    PE_DEV double finite_abs(double v) { return fabs(v) <= 1.7976931348623157e308 ? fabs(v) : __builtin_inf(); }
+    template <class Team>
+    PE_DEV void residual_norms(Team const& tm, DevView const& V, int b, double* rres, double (&out4)[4])
+    {
+        double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
+        double const* x = V.x + static_cast<long long>(b) * V.rows;
+        double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
+        double mr = 0.0, ma = 0.0, mx = 0.0, mb = 0.0;
+        for(int r = tm.tid(); r < V.rows; r += tm.size())
+        {
+            double acc = rhs[r], rowsum = 0.0;
+            int const e1 = V.csr_rp[r + 1];
+            for(int e = V.csr_rp[r]; e < e1; ++e)
+            {
+                double const av = a[V.slot_e ? V.slot_e[e] : e];
+                acc -= av * x[V.csr_ci[e]];
+                rowsum += fabs(av);
+            }
+            if(rres) rres[r] = acc;
+            mr = fmax(mr, finite_abs(acc));
+            ma = fmax(ma, finite_abs(rowsum));
+            mx = fmax(mx, finite_abs(x[r]));
+            mb = fmax(mb, finite_abs(rhs[r]));
+        }
+        out4[0] = mr;
+        out4[1] = ma;
+        out4[2] = mx;
+        out4[3] = mb;
+    }
+    PE_DEV double backward_error(double const (&n4)[4])
+    {
+        double const den = n4[1] * n4[2] + n4[3];
+        return den > 0.0 ? n4[0] / den : (n4[0] > 0.0 ? __builtin_inf() : 0.0);
+    }
+
     // per-thread part of the Newton convergence test; the team reduces the returned flag with OR
     template <class Team>
     PE_DEV int newton_violations(Team const& tm, DevView const& V, int b)
@@ -1299,6 +1342,15 @@ namespace pe
             for(int r = tm.tid(); r < V.rows; r += tm.size())
                 if(!(fabs(x[r]) <= 1.7976931348623157e308)) nonfinite = 1;
             if(tm.sync_or(nonfinite)) return ST_SINGULAR;
+            if(V.residual_tol > 0.0)
+            {
+                // The resident kernel only DETECTS an inaccurate solve (and fails the step like a Newton failure); the host then
+                // repeats it on the split schedule, whose host-driven loop refines / re-matches (pe_engine.cpp).
+                double n4[4];
+                residual_norms(tm, V, b, nullptr, n4);
+                tm.team_max4(n4, lds);
+                if(!(backward_error(n4) <= V.residual_tol)) return ST_INACCURATE;
+            }
             if(!V.nonlinear) return 1;
             int const viol = tm.sync_or(newton_violations(tm, V, b));
             if(V.prof && tm.tid() == 0) V.prof[b * PE_PROF + 4] += (c0 - cb0) + (tm.clock() - cb1);  // Newton bookkeeping

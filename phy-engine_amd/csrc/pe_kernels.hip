@@ -67,28 +67,55 @@ namespace pe
             __shared__ double rd[8];
             return rd;
         }
-        __device__ __forceinline__ int diag_lu8(double* blk, int ld, int kb, int lane) const
+        // LU (no pivoting) of the KB x KB diagonal block of a cooperative front, on ONE wavefront: lane i < KB holds row i in
+        // registers, the pivot row of step kk comes from lane kk by v_readlane (no LDS round trip on the dependent chain; the
+        // first version exchanged entries through ds_bpermute: three LDS latencies per pivot).  Same operation order as
+        // block_step_t's row part.  On return the block in LDS holds U on and above the diagonal and the SCALED multipliers
+        // below it, rdiag()[kk] the pivots' reciprocals.  Returns 1 on a bad pivot.
+        template <int KB>
+        __device__ __forceinline__ int diag_lu_t(double* blk, int ld, int lane) const
         {
-            int const r = lane & 7, c = lane >> 3;
-            bool const in = r < kb && c < kb;
-            double v = in ? blk[r + c * ld] : (r == c ? 1.0 : 0.0);
+            bool const own = lane < KB;
+            double* row = blk + (own ? lane : KB - 1);
+            double v[KB];
+#pragma unroll
+            for(int c = 0; c < KB; ++c) v[c] = row[c * ld];
             int bad = 0;
             double* rd = rdiag();
 #pragma unroll
-            for(int kk = 0; kk < 8; ++kk)
+            for(int kk = 0; kk < KB; ++kk)
             {
-                double const piv = __shfl(v, kk + 8 * kk);
-                double const lrk = __shfl(v, r + 8 * kk);
-                double const ukc = __shfl(v, kk + 8 * c);
-                if(kk < kb && (piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308))) bad = 1;
-                double const rp = rcp(piv);  // one reciprocal per pivot (every lane, in parallel), not a full divide per entry
-                rd[kk] = rp;                 // (every lane stores the same value)
-                double const l = lrk * rp;
-                if(r > kk && c > kk) v -= l * ukc;
-                if(r > kk && c == kk) v = l;
+                double const piv = bcast(v[kk], kk);
+                if(piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308)) bad = 1;
+                double const rp = rcp(piv);
+                rd[kk] = rp;  // (every lane stores the same value)
+                double const l = v[kk] * rp;
+                bool const below = lane > kk;
+                double const lm = below ? l : 0.0;
+#pragma unroll
+                for(int c = kk + 1; c < KB; ++c) v[c] = __builtin_fma(-lm, bcast(v[c], kk), v[c]);
+                v[kk] = below ? l : v[kk];
             }
-            if(in) blk[r + c * ld] = v;
+            if(own)
+            {
+#pragma unroll
+                for(int c = 0; c < KB; ++c) row[c * ld] = v[c];
+            }
             return bad;
+        }
+        __device__ __forceinline__ int diag_lu8(double* blk, int ld, int kb, int lane) const
+        {
+            switch(kb)
+            {
+                case 8: return diag_lu_t<8>(blk, ld, lane);
+                case 7: return diag_lu_t<7>(blk, ld, lane);
+                case 6: return diag_lu_t<6>(blk, ld, lane);
+                case 5: return diag_lu_t<5>(blk, ld, lane);
+                case 4: return diag_lu_t<4>(blk, ld, lane);
+                case 3: return diag_lu_t<3>(blk, ld, lane);
+                case 2: return diag_lu_t<2>(blk, ld, lane);
+                default: return diag_lu_t<1>(blk, ld, lane);
+            }
         }
         // Rows below a factored KB x KB diagonal block (x U11 = a) and columns right of it (L11 y = a), one thread each, the
         // block read through v_readlane from one entry per lane.  The split between rows and columns falls on a wavefront
@@ -335,6 +362,13 @@ namespace pe
             int const bi = ti < 31 ? ti : 31, bj = tj < 31 ? tj : 31;
             return __ballot((((mk >> bi) & (mk >> bj)) & 1u) != 0u);
         }
+        // max over the 64 lanes (every lane gets it)
+        __device__ __forceinline__ double wave_max(double v) const
+        {
+#pragma unroll
+            for(int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+            return v;
+        }
         // ---- 16 x 16 fp64 tiles on the matrix core: v_mfma_f64_16x16x4_f64.
         // The instruction takes A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15] from lane l and keeps
         // D[(l>>4) + 4r][l&15] in accumulator register r (cdna_hip_programming.md 3, "f64 MFMA does NOT use these maps").
@@ -462,6 +496,11 @@ namespace pe
             body(0, lane_, 64);
         }
         __device__ __forceinline__ WaveTeam wave_team(int) const { return *this; }
+        __device__ __forceinline__ void team_max4(double (&v)[4], double*) const
+        {
+#pragma unroll
+            for(int k = 0; k < 4; ++k) v[k] = wave_max(v[k]);
+        }
     };
 
     // the whole workgroup
@@ -491,6 +530,27 @@ namespace pe
             WaveTeam w;
             w.lane_ = lane;
             return w;
+        }
+        // every thread gets the workgroup's maxima of its four values (scratch: 4 doubles per wavefront of dynamic LDS)
+        __device__ __forceinline__ void team_max4(double (&v)[4], double* scratch) const
+        {
+            int const lane = static_cast<int>(threadIdx.x) & 63, w = static_cast<int>(threadIdx.x) >> 6, nw = static_cast<int>(blockDim.x) >> 6;
+            __syncthreads();  // (the scratch region may still be read by the phase before)
+#pragma unroll
+            for(int k = 0; k < 4; ++k)
+            {
+                v[k] = wave_max(v[k]);
+                if(lane == 0) scratch[4 * w + k] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for(int k = 0; k < 4; ++k)
+            {
+                double m = scratch[k];
+                for(int q = 1; q < nw; ++q) m = fmax(m, scratch[4 * q + k]);
+                v[k] = m;
+            }
+            __syncthreads();
         }
     };
 
@@ -569,7 +629,12 @@ namespace pe
         double* xp = V.xprev + static_cast<long long>(b) * V.rows;
         for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
         eval_devices(tm, V, b, mode, t, last_step);
-        if(tm.tid() == 0) V.flags[b] = 0;
+        if(tm.tid() == 0)
+        {
+            V.flags[b] = 0;
+            if(V.eta_acc)
+                for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
+        }
     }
 
     __global__ void __launch_bounds__(256) k_m2_stamp(DevView V)
@@ -691,6 +756,73 @@ namespace pe
         if(bits) atomicOr(V.flags + b, bits);
     }
 
+    // ---- residual safety net (pe_front.hpp residual_norms): the four norms of every active instance's last solve, combined over the
+    // workgroups by atomic max on the (non-negative) doubles' bit patterns; keep_x != 0 also stores r and a copy of x for refinement
+    __global__ void __launch_bounds__(256) k_m2_residual(DevView V, int keep_x)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double n4[4];
+        residual_norms(tm, V, b, keep_x ? V.rres + static_cast<long long>(b) * V.rows : nullptr, n4);
+        if(keep_x)
+        {
+            double const* x = V.x + static_cast<long long>(b) * V.rows;
+            double* xs = V.xsave + static_cast<long long>(b) * V.rows;
+            for(int r = tm.tid(); r < V.rows; r += tm.size()) xs[r] = x[r];
+        }
+        WaveOps wo;
+#pragma unroll
+        for(int k = 0; k < 4; ++k)
+        {
+            double const m = wo.wave_max(n4[k]);
+            if((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(V.eta_acc + 4 * b + k), static_cast<unsigned long long>(__double_as_longlong(m)));
+        }
+    }
+    // x = (solution before the correction solve) + (correction, still permuted in w); clears the instance's accumulators for the re-check
+    __global__ void __launch_bounds__(256) k_m2_refine_apply(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double const* w = V.w + static_cast<long long>(b) * V.rows;
+        double const* xs = V.xsave + static_cast<long long>(b) * V.rows;
+        double* x = V.x + static_cast<long long>(b) * V.rows;
+        for(int k = tm.tid(); k < V.rows; k += tm.size())
+        {
+            int const r = V.col_src[k];
+            x[r] = xs[r] + w[k];
+        }
+    }
+    __global__ void __launch_bounds__(64) k_m2_clear_eta(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+        if(b < V.batch && V.active[b])
+        {
+            V.flags[b] = 0;
+            for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
+        }
+    }
+    // the non-finite / Newton test of k_m2_finish on the (refined) x of the active instances
+    __global__ void __launch_bounds__(256) k_m2_retest(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        GridTeam tm;
+        double const* x = V.x + static_cast<long long>(b) * V.rows;
+        double const* xp = V.xprev + static_cast<long long>(b) * V.rows;
+        int bits = 0;
+        for(int r = tm.tid(); r < V.rows; r += tm.size())
+        {
+            double const xn = x[r];
+            if(!(fabs(xn) <= 1.7976931348623157e308)) bits |= 1;
+            bool const node = r < V.n_nodes;
+            double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * fmax(fabs(xn), fabs(xp[r]));
+            if(!(fabs(xn - xp[r]) <= tol)) bits |= 2;
+        }
+        if(bits) atomicOr(V.flags + b, bits);
+    }
+
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-function upper bound: raised when a launch needs more than any launch
     // before it, never per launch (a Newton iteration of the split schedule is ~16 launches; engines on several host threads
     // share the table)
@@ -745,7 +877,7 @@ namespace pe
     // ev0 / ev1 (may be null): HIP events recorded around the dominant launch (k_m2_factor_parts, or the backward
     // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
     template <int MINW>
-    static hipError_t m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1)
+    static hipError_t m2_sequence(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1, bool refine)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
@@ -774,8 +906,12 @@ namespace pe
                 while(l - n >= 0 && V.top_cnt[l - n] == 1) ++n;
             return n;
         };
-        hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
-        hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
+        if(!refine)
+        {
+            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
+            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
+        }
+        // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)
         hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
         if(do_factor)
         {
@@ -806,13 +942,36 @@ namespace pe
         if(!do_factor && ev0) (void)hipEventRecord(ev0, st);
         hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 1);
         if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
-        hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);
+        if(!refine)
+        {
+            hipLaunchKernelGGL(k_m2_finish, dim3(G, B), dim3(256), 0, st, V);
+            if(V.residual_tol > 0.0) hipLaunchKernelGGL(k_m2_residual, dim3(G, B), dim3(256), 0, st, V, 0);
+        }
         return hipGetLastError();
     }
 
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1)
     {
-        return V.high_occupancy ? m2_iteration<4>(st, V, mode, t, last_step, do_factor, ev0, ev1) : m2_iteration<2>(st, V, mode, t, last_step, do_factor, ev0, ev1);
+        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false)
+                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false);
+    }
+
+    // One round of iterative refinement of the active instances' last solve (same matrix values, same pivot order):
+    // r = b - A x -> correction solve A d = r (a full refactorisation with r riding along: the fused path keeps no L21) -> x += d,
+    // then the norms of the corrected solve and its Newton / finiteness bits.
+    hipError_t launch_m2_refine(hipStream_t st, DevView const& V)
+    {
+        int const B = V.batch, G = grid_per_instance(V);
+        hipLaunchKernelGGL(k_m2_residual, dim3(G, B), dim3(256), 0, st, V, 1);
+        DevView Vr = V;
+        Vr.rhs = V.rres;
+        hipError_t const e = V.high_occupancy ? m2_sequence<4>(st, Vr, 0, 0.0, 0.0, true, nullptr, nullptr, true) : m2_sequence<2>(st, Vr, 0, 0.0, 0.0, true, nullptr, nullptr, true);
+        if(e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_m2_refine_apply, dim3(G, B), dim3(256), 0, st, V);
+        hipLaunchKernelGGL(k_m2_clear_eta, dim3((B + 63) / 64), dim3(64), 0, st, V);
+        hipLaunchKernelGGL(k_m2_residual, dim3(G, B), dim3(256), 0, st, V, 0);
+        hipLaunchKernelGGL(k_m2_retest, dim3(G, B), dim3(256), 0, st, V);
+        return hipGetLastError();
     }
 
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt)
@@ -876,6 +1035,28 @@ namespace pe
         dim3 const grid((V.rows + 255) / 256, n_chunks);
         hipLaunchKernelGGL(k_sweep_stats_partial, grid, dim3(256), 0, st, V.x, V.rows, V.batch, chunk_len, partial);
         hipLaunchKernelGGL(k_sweep_stats_final, dim3(grid.x), dim3(256), 0, st, partial, V.rows, n_chunks, out);
+        return hipGetLastError();
+    }
+
+    // ---- on-box HBM ceiling: device-to-device stream copy, 16 B per lane, four loads in flight per lane
+    using v4f_t = __attribute__((ext_vector_type(4))) float;
+    __global__ void __launch_bounds__(256) k_stream_copy(v4f_t const* __restrict__ src, v4f_t* __restrict__ dst, size_t n)
+    {
+        size_t const stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+        size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+        for(; i + 3 * stride < n; i += 4 * stride)
+        {
+            v4f_t const a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+            dst[i] = a;
+            dst[i + stride] = b;
+            dst[i + 2 * stride] = c;
+            dst[i + 3 * stride] = d;
+        }
+        for(; i < n; i += stride) dst[i] = src[i];
+    }
+    hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes)
+    {
+        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, st, static_cast<v4f_t const*>(src), static_cast<v4f_t*>(dst), bytes / 16);
         return hipGetLastError();
     }
 

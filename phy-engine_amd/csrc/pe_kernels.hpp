@@ -19,6 +19,10 @@ namespace pe
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt);
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0 = nullptr,
                                    hipEvent_t ev1 = nullptr);
+    // device-to-device stream copy of `bytes` (multiple of 16): the kernel behind pe_hip_measure_hbm_ceiling
+    hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes);
+    // one round of iterative refinement of the active instances' last solve + re-check (residual safety net, pe_front.hpp)
+    hipError_t launch_m2_refine(hipStream_t st, DevView const& V);
     // per-row {sum v, sum v^2, min, max} of x over the instances (the payload of the sweep's one exchange step):
     // `partial` holds n_chunks x 4 x rows doubles, `out` 4 x rows (both device memory); deterministic (fixed chunk order)
     hipError_t launch_sweep_statistics(hipStream_t st, DevView const& V, int n_chunks, double* partial, double* out);

@@ -19,13 +19,13 @@ IAC, VCCS, VCVS, CCCS, CCVS, OPAMP, XFMR, SWITCH, VGEN, COUPLED_L = 8, 9, 10, 11
 NMOS, PMOS, BJT_NPN, BJT_PNP, RELAY, XFMR_CT = 18, 19, 20, 21, 22, 23
 DIODE_NPARAM = 11
 MODE_OP, MODE_DC, MODE_TR, MODE_TROP = 0, 1, 4, 5
-OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL = 0, -1, -2, -3, -4, -5
+OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL, ERR_INACCURATE = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
     "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real",
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
-    "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
+    "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_measure_hbm_ceiling", "pe_hip_get_safety_net_counters", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
     "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",
 ]
 
@@ -37,7 +37,7 @@ class DeviceTable(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("v_abstol", C.c_double), ("v_reltol", C.c_double), ("i_abstol", C.c_double), ("i_reltol", C.c_double),
-                ("g_min", C.c_double), ("max_newton", C.c_int), ("refactor_every_solve", C.c_int), ("r_open", C.c_double)]
+                ("g_min", C.c_double), ("max_newton", C.c_int), ("refactor_every_solve", C.c_int), ("r_open", C.c_double), ("residual_tol", C.c_double)]
 
 
 class Timings(C.Structure):
@@ -89,6 +89,8 @@ def lib():
         l.pe_hip_get_solution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         l.pe_hip_set_solution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         l.pe_hip_sweep_statistics.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        l.pe_hip_get_safety_net_counters.argtypes = [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+        l.pe_hip_measure_hbm_ceiling.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
         l.pe_hip_get_instance_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong),
                                                 C.POINTER(C.c_longlong), C.POINTER(C.c_double)]
         l.pe_hip_get_newton_trace.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -229,8 +231,8 @@ class Engine:
             raise PeHipError(rc, lib().pe_hip_last_error(self._h).decode())
         return rc
 
-    def set_options(self, g_min=0.0, v_abstol=0.0, v_reltol=0.0, i_abstol=0.0, i_reltol=0.0, max_newton=0, refactor_every_solve=1, r_open=0.0):
-        o = Options(v_abstol, v_reltol, i_abstol, i_reltol, g_min, max_newton, refactor_every_solve, r_open)
+    def set_options(self, g_min=0.0, v_abstol=0.0, v_reltol=0.0, i_abstol=0.0, i_reltol=0.0, max_newton=0, refactor_every_solve=1, r_open=0.0, residual_tol=0.0):
+        o = Options(v_abstol, v_reltol, i_abstol, i_reltol, g_min, max_newton, refactor_every_solve, r_open, residual_tol)
         self._chk(lib().pe_hip_set_options(self._h, C.byref(o)))
 
     def set_digital_drives(self, nodes, volts):
@@ -282,6 +284,18 @@ class Engine:
         x = np.empty((count, self.rows))
         self._chk(lib().pe_hip_get_solution(self._h, first, count, _dp(x)))
         return x
+
+    def safety_net(self):
+        """{'refined': solves repaired by refinement, 'rematched': symbolic re-analyses, 'careful': host-driven schedule forced}."""
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        self._chk(lib().pe_hip_get_safety_net_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"refined": a.value, "rematched": b.value, "careful": bool(c.value)}
+
+    def measure_hbm_ceiling(self, nbytes=1 << 31, reps=5):
+        """GB/s of a device-to-device stream copy on this engine's GPU (read + written bytes / HIP-event time)."""
+        g = C.c_double(0.0)
+        self._chk(lib().pe_hip_measure_hbm_ceiling(self._h, C.c_size_t(nbytes), int(reps), C.byref(g)))
+        return g.value
 
     def sweep_statistics(self):
         """[4][rows]: sum, sum of squares, min, max of the current solution over this engine's instances (computed on the device)."""

@@ -1,6 +1,8 @@
 // tests/emu/pe_kernels_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the team-generic code of pe_front.hpp on the host
 // with a one-thread team per instance and one-lane "wavefronts" executed one after the other (see
 // hip_shim/hip/hip_runtime_api.h).  Checks indexing and the orchestration; says nothing about races or performance.
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "pe_front.hpp"
@@ -8,13 +10,24 @@
 
 namespace pe
 {
+    // Test knob of the emulation ONLY (tests/test_host_logic.py: residual safety net): every pivot reciprocal is taken with a relative
+    // error PE_EMU_PIVOT_ERROR, i.e. a deliberately inexact LU whose solves leave residuals that iterative refinement must repair.
+    static double emu_rcp(double d)
+    {
+        static double const eps = [] {
+            char const* v = std::getenv("PE_EMU_PIVOT_ERROR");
+            return v && *v ? std::atof(v) : 0.0;
+        }();
+        return (1.0 / d) * (1.0 + eps);
+    }
+
     struct SerialTeam
     {
         int nw;
         SerialTeam wave_team(int) const { return SerialTeam{1}; }
         int tid() const { return 0; }
         int uniform(int v) const { return v; }
-        double rcp(double d) const { return 1.0 / d; }
+        double rcp(double d) const { return emu_rcp(d); }
         void sync_lds() const {}
         int size() const { return 1; }
         void sync() const {}
@@ -29,6 +42,7 @@ namespace pe
         }
         int n_waves() const { return nw; }
         bool single_wave() const { return nw == 1; }
+        void team_max4(double (&)[4], double*) const {}  // one thread: its partial maxima are the team's
         struct Blk8
         {
             double const* p;
@@ -42,7 +56,7 @@ namespace pe
             {
                 double const piv = Lp[(k0 + kk) + (k0 + kk) * m];
                 if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
-                double const r = 1.0 / piv;
+                double const r = emu_rcp(piv);
                 for(int i = k0 + kk + 1; i < m; ++i)
                 {
                     double const l = Lp[i + (k0 + kk) * m] * r;
@@ -70,7 +84,7 @@ namespace pe
                 {
                     double acc = row[kk * m];
                     for(int r = 0; r < kk; ++r) acc -= row[r * m] * blk[r + kk * m];
-                    row[kk * m] = acc * (1.0 / blk[kk + kk * m]);
+                    row[kk * m] = acc * emu_rcp(blk[kk + kk * m]);
                 }
             }
             int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
@@ -89,7 +103,7 @@ namespace pe
                 if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
                 for(int r = kk + 1; r < kb; ++r)
                 {
-                    double const l = blk[r + kk * ld] * (1.0 / piv);
+                    double const l = blk[r + kk * ld] * emu_rcp(piv);
                     for(int c = kk + 1; c < kb; ++c) blk[r + c * ld] -= l * blk[kk + c * ld];
                     blk[r + kk * ld] = l;
                 }
@@ -195,6 +209,8 @@ namespace pe
             for(int r = 0; r < V.rows; ++r) xp[r] = x[r];
             eval_devices(tm, V, b, mode, t, last_step);
             V.flags[b] = 0;
+            if(V.eta_acc)
+                for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
             stamp(tm, V, b);
             for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
             if(do_factor)
@@ -224,7 +240,56 @@ namespace pe
                 double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * std::fmax(std::fabs(xn), std::fabs(xp[r]));
                 if(!(std::fabs(xn - xp[r]) <= tol)) V.flags[b] |= 2;
             }
+            if(V.residual_tol > 0.0)
+            {
+                double n4[4];
+                residual_norms(tm, V, b, nullptr, n4);
+                for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = n4[k];
+            }
         }
+        return hipSuccess;
+    }
+    hipError_t launch_m2_refine(hipStream_t, DevView const& V)
+    {
+        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        SerialTeam tm{V.n_waves};
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double const* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* xs = V.xsave + static_cast<long long>(b) * V.rows;
+            double* rr = V.rres + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
+            double n4[4];
+            residual_norms(tm, V, b, rr, n4);
+            for(int r = 0; r < V.rows; ++r) xs[r] = x[r];
+            for(int k = 0; k < V.rows; ++k) w[k] = rr[V.row_src[k]];
+            for(int q = 0; q < V.n_parts; ++q)
+                if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
+            for(int l = 0; l < V.n_top_levels; ++l)
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
+                    if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, 0, true)) V.flags[b] |= 4;
+            for(int l = V.n_top_levels - 1; l >= 0; --l)
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+            for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
+            for(int k = 0; k < V.rows; ++k) x[V.col_src[k]] = xs[V.col_src[k]] + w[k];
+            V.flags[b] = 0;
+            residual_norms(tm, V, b, nullptr, n4);
+            for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = n4[k];
+            for(int r = 0; r < V.rows; ++r)
+            {
+                if(!(std::fabs(x[r]) <= 1.7976931348623157e308)) V.flags[b] |= 1;
+                bool const node = r < V.n_nodes;
+                double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * std::fmax(std::fabs(x[r]), std::fabs(xp[r]));
+                if(!(std::fabs(x[r] - xp[r]) <= tol)) V.flags[b] |= 2;
+            }
+        }
+        return hipSuccess;
+    }
+    hipError_t launch_stream_copy(hipStream_t, void const* src, void* dst, size_t bytes)
+    {
+        std::memcpy(dst, src, bytes);
         return hipSuccess;
     }
     hipError_t launch_sweep_statistics(hipStream_t, DevView const& V, int n_chunks, double* partial, double* out)

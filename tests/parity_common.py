@@ -87,3 +87,31 @@ def run_ac_case(eng, meta, deck):
 def golden_complex(meta, gx):
     n = meta["rows"]
     return gx[:, :n] + 1j * gx[:, n:]
+
+
+def adversarial_pivot_sweep():
+    """Decks of the residual-safety-net test: ONE topology, two instances whose values call for different pivot orders.
+    A 1 V source drives a resistive ladder (12 series arms, shunts to ground) through a switch in the middle.
+      instance 0  switch closed (branch diagonal D = 0), every resistor 1 kOhm
+      instance 1  switch open (D = -r_open = -1e12) and the right half of the ladder scaled by 1e6 (1 GOhm beside 1 kOhm)
+    The static pivot order is matched on instance 0's values.  Returns (deck0, deck1, batched overrides)."""
+    n = 12
+
+    def build(closed, scale):
+        d = pe.deck.Deck()
+        d.n_nodes = n + 2
+        d.add("VDC", (1, 0), 1.0)
+        for i in range(1, n + 1):
+            r = 1000.0 * (scale if i > n // 2 else 1.0)
+            a, b = i, i + 1
+            if i == n // 2:
+                d.add("SW", (a, n + 2), 1.0 if closed else 0.0)   # the switch sits in series with this arm
+                a = n + 2
+            d.add("R", (a, b), r)
+            d.add("R", (b, 0), 2.0 * r)
+        return d
+
+    d0, d1 = build(True, 1.0), build(False, 1e6)
+    rr = np.array([[p[0] for k, _, p in d.devices if k == "R"] for d in (d0, d1)])[:, :, None]
+    sw = np.array([[p[0] for k, _, p in d.devices if k == "SW"] for d in (d0, d1)])[:, :, None]
+    return d0, d1, {"R": rr, "SW": sw}

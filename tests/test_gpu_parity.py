@@ -721,3 +721,52 @@ def test_c5_sweep_1024_instances_parity_and_statistics():
             assert max_err(x100[k], gx[gm["snap_steps"].index(100)], *NL) <= 1.0, f"seed {k + 1} at step 100"
     finally:
         e.close()
+
+
+def test_residual_safety_net_paths_on_gpu():
+    """The residual safety net of the static-pivot LU on the device (k_m2_residual / k_m2_refine_apply / k_m2_retest and the resident
+    kernel's check).  An unreachable residual_tol drives every stage: detection in the resident kernel, the switch to the
+    host-driven schedule, two refinement rounds, a re-match on the instance's own values, and finally PE_HIP_ERR_INACCURATE with
+    the step rolled back; the failure is not sticky.  With the default tolerance the same transient must run without any
+    intervention (no false alarm) -- as every other golden test implicitly checks -- and a 2-instance sweep with an open /
+    closed switch and a 1e6 resistor scale must match the oracle per instance."""
+    meta, gx, deck = golden("mesh32_nl")
+    g10 = gx[meta["snap_steps"].index(10)]
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0, residual_tol=1e-30)
+        e.load_deck(deck)
+        e.reset()
+        st = e.analyze_tr(1e-10, 10, check=False)
+        assert st["rc"] == pe.ffi.ERR_INACCURATE and st["steps"] == 0
+        s = e.state()
+        assert s["t"][0] == 0.0 and s["status"][0] == pe.ffi.ERR_INACCURATE
+        sn = e.safety_net()
+        assert sn["careful"] and sn["rematched"] >= 1
+        e.set_options(g_min=0.0, residual_tol=0.0)
+        st = e.analyze_tr(1e-10, 10, check=False)          # careful schedule (refining), sane tolerance: continues from t = 0
+        assert st["rc"] == 0 and st["steps"] == 10 and np.all(np.isfinite(e.solution()[0]))  # (a valid continuation, as in the reference)
+    finally:
+        e.close()
+    e = pe.ffi.Engine(device=0)
+    try:
+        e.set_options(g_min=0.0)
+        e.load_deck(deck)
+        e.reset()
+        e.analyze_tr(1e-10, 10)
+        assert max_err(e.solution()[0], g10, *NL) <= 1.0
+        assert e.safety_net() == {"refined": 0, "rematched": 0, "careful": False}
+        from parity_common import adversarial_pivot_sweep
+        import pe_load
+        orc = pe_load.load_oracle()
+        d0, d1, ov = adversarial_pivot_sweep()
+        e.load_deck(d0, batch=2, overrides=ov)
+        e.reset()
+        e.analyze_dc(pe.ffi.MODE_DC)
+        x = e.solution()
+        for k, d in enumerate((d0, d1)):
+            o = orc.Oracle(d)
+            o.analyze_dc("DC")
+            assert max_err(x[k], o.x, *LIN) <= 1.0
+    finally:
+        e.close()

@@ -331,3 +331,56 @@ assert s1['status'][0] == 0 and abs(float(s1['t'][0]) - (n_ok + 50) * meta['dt']
 assert np.all(np.isfinite(eng.solution()[0]))
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
+def test_residual_safety_net_under_host_emulation(emu_lib):
+    """Static pivoting with a safety net (the reference pivots partially, Eigen SparseLU.h:464-469): after every linear solve the
+    normwise backward error is checked per instance; above residual_tol the solve is refined (correction solve on the residual),
+    else the pivot order is re-matched on that instance's values, else the step fails as PE_HIP_ERR_INACCURATE and is rolled back.
+      (a) an LU made inexact on purpose (emulation-only knob PE_EMU_PIVOT_ERROR: every pivot reciprocal off by 1e-7) gives a
+          visibly wrong transient without the net and the golden transient with it -- every solve repaired by refinement;
+      (b) an unreachable tolerance exercises the failure path: refinement and re-matching both give up, the step is rolled back,
+          and the failure is not sticky (the next analyze() with a sane tolerance continues);
+      (c) a 2-instance sweep whose instance 1 opens a switch (r_open = 1e12 where instance 0 has 0) and scales half the resistors
+          by 1e6, solved with the pivot order matched on instance 0: both at oracle accuracy, no false alarm."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))
+import numpy as np
+from parity_common import adversarial_pivot_sweep, golden, pe, max_err
+import pe_load
+meta, gx, deck = golden('mesh32_nl')
+g10 = gx[meta['snap_steps'].index(10)]
+def run(tol):
+    eng = pe.ffi.Engine(); eng.set_options(g_min=0.0, residual_tol=tol); eng.load_deck(deck); eng.reset()
+    st = eng.analyze_tr(1e-10, 10, check=False)
+    return eng, st
+if os.environ.get('PE_EMU_PIVOT_ERROR'):
+    eng, st = run(-1.0)                                   # (a) net disabled: inexact LU goes through
+    assert st['rc'] == 0 and max_err(eng.solution()[0], g10, 1e-9, 1e-7) > 1.0
+    eng, st = run(0.0)                                    # default tolerance 1e-10
+    assert st['rc'] == 0 and st['steps'] == 10, st
+    assert max_err(eng.solution()[0], g10, 1e-9, 1e-7) <= 1.0
+    sn = eng.safety_net(); assert sn['refined'] >= 10 and sn['careful'], sn
+else:
+    eng, st = run(1e-30)                                  # (b)
+    assert st['rc'] == pe.ffi.ERR_INACCURATE and st['steps'] == 0, st
+    s = eng.state(); assert s['t'][0] == 0.0 and s['status'][0] == pe.ffi.ERR_INACCURATE
+    sn = eng.safety_net(); assert sn['careful'] and sn['rematched'] >= 1, sn
+    eng.set_options(g_min=0.0, residual_tol=0.0)
+    st = eng.analyze_tr(1e-10, 10, check=False)
+    # (like the reference, the retried step re-applies update_tr_step on the failed iterate: the continuation is a valid run, not the golden one)
+    assert st['rc'] == 0 and st['steps'] == 10 and np.all(np.isfinite(eng.solution()[0]))
+    orc = pe_load.load_oracle()                           # (c)
+    d0, d1, ov = adversarial_pivot_sweep()
+    e2 = pe.ffi.Engine(); e2.set_options(g_min=0.0); e2.load_deck(d0, batch=2, overrides=ov); e2.reset()
+    e2.analyze_dc(pe.ffi.MODE_DC)
+    x = e2.solution()
+    for k, d in enumerate((d0, d1)):
+        o = orc.Oracle(d); o.analyze_dc('DC')
+        assert max_err(x[k], o.x, 1e-9, 1e-7) <= 1.0, (k, np.max(np.abs(x[k] - o.x)))
+    assert e2.safety_net() == {{'refined': 0, 'rematched': 0, 'careful': False}}
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
+    subprocess.run(["python3", "-c", code], check=True, timeout=300, env=dict(os.environ, PE_EMU_PIVOT_ERROR="1e-7"))
