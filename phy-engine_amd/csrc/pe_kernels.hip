@@ -920,9 +920,11 @@ namespace pe
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
             static bool const wide_knob = getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;
-            bool const wide = MINW == 2 && wide_knob;  // one workgroup per CU anyway (LDS plan); (developer knob for A/B runs)
             for(int l = 0; l < V.n_top_levels; l += run(l))
             {
+                // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
+                // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %)
+                bool const wide = wide_knob && (MINW == 2 || V.top_cnt[l] * B <= 320);
                 if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), lds, st, V, l, run(l));
                 else
                     hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
