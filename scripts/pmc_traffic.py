@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Developer tool: profiles/r01_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/profile_round.sh.
+"""Developer tool: profiles/r02_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/profile_round.sh.
 
   python scripts/pmc_traffic.py gpurun_out/<tag>_fetch gpurun_out/<tag>_write gpurun_out/<tag>_bench.json [kernel substring]
 
 Sums FETCH_SIZE / WRITE_SIZE (KiB) over the dispatches of the dominant kernel and divides by their count: HBM bytes per
-launch, the same normalisation as roofline.achieved in bench.py.  Raw KiB x 1024, not doubled (see "note")."""
+launch, the same normalisation as roofline.achieved in bench.py.  FETCH_SIZE / WRITE_SIZE (KiB) are converted with the factors
+calibrated on this engine's access shapes (profiles/r02_hbm_calib.json from scripts/hbm_calib.hip: FETCH x 2.0, WRITE x 1.0)."""
 import csv, glob, json, os, sys
 
 fetch_dir, write_dir, bench_json = sys.argv[1:4]
@@ -25,14 +26,20 @@ def total(d, counter):
 f, nf = total(fetch_dir, "FETCH_SIZE")
 w, nw = total(write_dir, "WRITE_SIZE")
 assert nf and nf == nw, (nf, nw)
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+cal = json.load(open(os.path.join(root, "profiles", "r02_hbm_calib.json")))
+ff, wf = cal["fetch_factor_for_this_engine"], cal["write_factor_for_this_engine"]
 out = {
-    "instances_per_gpu": line["config"]["instances_per_gpu"], "nonlinear": "-NL" in line["config"]["workload"], "mesh": 100,
+    "instances_per_gpu": line["config"]["instances_rank0"], "nonlinear": "-NL" in line["config"]["workload"], "mesh": 100,
     "kernel": kernel, "dispatches": nf, "FETCH_SIZE_KiB_per_launch": f / nf, "WRITE_SIZE_KiB_per_launch": w / nw,
-    "hbm_bytes_per_launch": (f / nf + w / nw) * 1024.0,
+    "fetch_factor": ff, "write_factor": wf,
+    "read_bytes_per_launch": f / nf * 1024.0 * ff, "written_bytes_per_launch": w / nw * 1024.0 * wf,
+    "hbm_bytes_per_launch": f / nf * 1024.0 * ff + w / nw * 1024.0 * wf,
     "algorithmic_bytes_per_launch": line["roofline"]["bytes_per_launch"],
-    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --no-cpu-baseline --no-single`, "
-            "averaged over every dispatch of the kernel (warm-up included: same work per launch up to the converged instances); raw KiB x 1024, "
-            "NOT doubled: the guide's x2 FETCH_SIZE correction is calibrated for 16-B/lane streams, this kernel's 8-B/lane gather pattern is uncalibrated",
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --no-cpu-baseline --no-single`, averaged over "
+            "every dispatch of the kernel (warm-up included: same work per launch up to the converged instances); KiB x 1024 x the factor calibrated "
+            "for this engine's access shapes on the same kind of box (profiles/r02_hbm_calib.json: FETCH_SIZE reports half of the bytes read)",
 }
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json"), "w"), indent=1)
+out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+json.dump(out, open(os.path.join(root, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
