@@ -794,6 +794,72 @@ namespace pe
                     };
                     auto nxt = tm.tile_zero();
                     if(chain && w < nt * nt) nxt = chain_tile(w);
+                    if(staged)
+                    {
+                        // PANEL layout: software-pipelined over this wavefront's tiles -- the first two children of the NEXT tile are
+                        // requested before the rank-p product of the current one, so a tile costs max(pull latency, product), not the sum.
+                        // Only the children that touch a tile's row block AND column block are pulled (one ballot over the staged masks).
+                        auto pull = [&](int q, int i0, int j0, int mr, int nc)
+                        {
+                            auto raw = tm.tile_zero();
+                            int const uc = cuc[q];
+                            double const* Sc = arena + csp[q];
+                            int const* inv = linv + q * u;
+                            tm.tile_foreach(raw, lane,
+                                            [&](int r, int c, double& v)
+                                            {
+                                                bool const in = r < mr && c < nc;
+                                                int const ci = in ? inv[i0 + r] : -1, cj = in ? inv[j0 + c] : -1;
+                                                double const* src = (ci >= 0 && cj >= 0) ? Sc + (ci + cj * uc) : V.zero;
+                                                v = *src;
+                                            });
+                            return raw;
+                        };
+                        auto first_two = [&](int tile, decltype(tm.tile_zero())& r0, decltype(tm.tile_zero())& r1)
+                        {
+                            int const tj = tile / nt, ti = tile - tj * nt;
+                            int const i0 = 16 * ti, j0 = 16 * tj;
+                            int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
+                            auto todo = tm.tile_children(cmk, nch, ti, tj, lane);
+                            r0 = tm.tile_zero();
+                            r1 = tm.tile_zero();
+                            if(todo)
+                            {
+                                r0 = pull(__builtin_ctzll(todo), i0, j0, mr, nc);
+                                todo &= todo - 1;
+                            }
+                            if(todo)
+                            {
+                                r1 = pull(__builtin_ctzll(todo), i0, j0, mr, nc);
+                                todo &= todo - 1;
+                            }
+                            return todo;  // children still to pull for this tile
+                        };
+                        auto n0 = tm.tile_zero(), n1 = tm.tile_zero();
+                        decltype(tm.tile_children(cmk, nch, 0, 0, lane)) rest_next = 0;
+                        if(w < nt * nt) rest_next = first_two(w, n0, n1);
+                        for(int tile = w; tile < nt * nt; tile += NW)
+                        {
+                            int const tj = tile / nt, ti = tile - tj * nt;
+                            int const i0 = 16 * ti, j0 = 16 * tj;
+                            int const mr = u - i0 < 16 ? u - i0 : 16, nc = u - j0 < 16 ? u - j0 : 16;
+                            auto const raw0 = n0, raw1 = n1;
+                            auto rest = rest_next;
+                            if(tile + NW < nt * nt) rest_next = first_two(tile + NW, n0, n1);
+                            auto acc = tm.tile_zero();
+                            tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
+                            tm.tile_add(acc, raw0);
+                            tm.tile_add(acc, raw1);
+                            while(rest)
+                            {
+                                auto const rq = pull(__builtin_ctzll(rest), i0, j0, mr, nc);
+                                rest &= rest - 1;
+                                tm.tile_add(acc, rq);
+                            }
+                            tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
+                        }
+                        return;
+                    }
                     for(int tile = w; tile < nt * nt; tile += NW)
                     {
                         int const tj = tile / nt, ti = tile - tj * nt;
@@ -808,52 +874,6 @@ namespace pe
                         }
                         else
                         {
-                            if(staged)
-                            {
-                                // every child's metadata and inverse map come from LDS, every load from the children's
-                                // update matrices is unconditional (lanes without a contribution read a 0.0 parked in device
-                                // memory): the loads of several children are in flight together.  The first two children are
-                                // requested BEFORE the rank-p product and added after it, so their latency hides behind the MFMAs.
-                                auto pull = [&](int q)
-                                {
-                                    auto raw = tm.tile_zero();
-                                    int const uc = cuc[q];
-                                    double const* Sc = arena + csp[q];
-                                    int const* inv = linv + q * u;
-                                    tm.tile_foreach(raw, lane,
-                                                    [&](int r, int c, double& v)
-                                                    {
-                                                        bool const in = r < mr && c < nc;
-                                                        int const ci = in ? inv[i0 + r] : -1, cj = in ? inv[j0 + c] : -1;
-                                                        double const* src = (ci >= 0 && cj >= 0) ? Sc + (ci + cj * uc) : V.zero;
-                                                        v = *src;
-                                                    });
-                                    return raw;
-                                };
-                                // only the children that touch this tile's row block AND column block are pulled (a front that
-                                // absorbed many children sees two or three of them per tile): one ballot over the staged block masks
-                                auto todo = tm.tile_children(cmk, nch, ti, tj, lane);
-                                auto pop = [&]()
-                                {
-                                    int const q = __builtin_ctzll(todo);
-                                    todo &= todo - 1;
-                                    return q;
-                                };
-                                auto raw0 = tm.tile_zero(), raw1 = tm.tile_zero();
-                                if(todo) raw0 = pull(pop());
-                                if(todo) raw1 = pull(pop());
-                                tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
-                                tm.tile_add(acc, raw0);
-                                tm.tile_add(acc, raw1);
-                                while(todo)
-                                {
-                                    auto const rq = pull(pop());
-                                    tm.tile_add(acc, rq);
-                                }
-                                tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
-                                continue;
-                            }
-                            else
                             {
                                 for(int ch = ch0; ch < ch1; ++ch)
                                 {
@@ -1342,19 +1362,21 @@ namespace pe
             for(int r = tm.tid(); r < V.rows; r += tm.size())
                 if(!(fabs(x[r]) <= 1.7976931348623157e308)) nonfinite = 1;
             if(tm.sync_or(nonfinite)) return ST_SINGULAR;
-            if(V.residual_tol > 0.0)
+            // Residual safety net: the iterate that is about to be ACCEPTED is checked (a linear solve, or the Newton iterate that passed
+            // the convergence test).  The resident kernel only DETECTS an inaccurate solve (and fails the step like a Newton failure);
+            // the host then repeats it on the split schedule, whose host-driven loop refines / re-matches (pe_engine.cpp).
+            auto accurate = [&]() -> bool
             {
-                // The resident kernel only DETECTS an inaccurate solve (and fails the step like a Newton failure); the host then
-                // repeats it on the split schedule, whose host-driven loop refines / re-matches (pe_engine.cpp).
+                if(!(V.residual_tol > 0.0)) return true;
                 double n4[4];
                 residual_norms(tm, V, b, nullptr, n4);
                 tm.team_max4(n4, lds);
-                if(!(backward_error(n4) <= V.residual_tol)) return ST_INACCURATE;
-            }
-            if(!V.nonlinear) return 1;
+                return backward_error(n4) <= V.residual_tol;
+            };
+            if(!V.nonlinear) return accurate() ? 1 : ST_INACCURATE;
             int const viol = tm.sync_or(newton_violations(tm, V, b));
             if(V.prof && tm.tid() == 0) V.prof[b * PE_PROF + 4] += (c0 - cb0) + (tm.clock() - cb1);  // Newton bookkeeping
-            if(!viol) return it + 1;
+            if(!viol) return accurate() ? it + 1 : ST_INACCURATE;
         }
         return ST_NO_CONVERGENCE;
     }

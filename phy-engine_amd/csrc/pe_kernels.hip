@@ -762,6 +762,10 @@ namespace pe
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
+        // only an iterate that is about to be ACCEPTED is checked: a non-linear instance whose Newton test (k_m2_finish, the launch
+        // before this one) still shows a violation iterates again anyway -- one residual pass per instance and time point, not per
+        // Newton iteration (its accumulators stay 0: "not above tolerance")
+        if(V.nonlinear && !keep_x && (V.flags[b] & 2)) return;
         GridTeam tm;
         double n4[4];
         residual_norms(tm, V, b, keep_x ? V.rres + static_cast<long long>(b) * V.rows : nullptr, n4);

@@ -240,7 +240,7 @@ namespace pe
                 double const tol = (node ? V.v_abstol : V.i_abstol) + (node ? V.v_reltol : V.i_reltol) * std::fmax(std::fabs(xn), std::fabs(xp[r]));
                 if(!(std::fabs(xn - xp[r]) <= tol)) V.flags[b] |= 2;
             }
-            if(V.residual_tol > 0.0)
+            if(V.residual_tol > 0.0 && !(V.nonlinear && (V.flags[b] & 2)))  // (only an iterate about to be accepted, as k_m2_residual)
             {
                 double n4[4];
                 residual_norms(tm, V, b, nullptr, n4);
