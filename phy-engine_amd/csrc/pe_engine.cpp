@@ -93,6 +93,7 @@ struct pe_hip_engine
     pe_hip_overlay_fn overlay_fn{};
     void* overlay_user{};
     std::vector<double> ov_x, ov_a, ov_b;  // staging of the callback
+    bool singular_rematched{};    // the one re-match after a singular pivot has been spent for this resident circuit
     bool careful{};               // residual safety net tripped on the resident kernel: stay on the host-driven (refining) schedule
     long long n_refined{}, n_rematched{};  // solves repaired by refinement / symbolic re-analyses on an instance's own values (diagnostics)
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
@@ -101,6 +102,7 @@ struct pe_hip_engine
     Pool sym_pool;   // symbolic arrays + factor storage
     pe::Symbolic sym;
     int sym_class{-1};  // 0: static (OP/DC/TROP) pattern weights, 1: TR
+    double sym_dt{};    // time step whose companion values the TR analysis was matched on
     pe::DevView V{};
     bool fact_valid{};
     double fact_dt{};
@@ -391,7 +393,11 @@ namespace
     int ensure_symbolic(pe_hip_engine* h, bool tr, double dt)
     {
         int const cls = tr ? 1 : 0;
-        if(h->sym_class == cls) return PE_HIP_OK;
+        // the static pivot order was matched on representative values at ONE dt (capacitor / inductor companions scale with 1/dt):
+        // a time step more than a decade away from it gets a fresh analysis, like a change of class
+        bool const dt_moved = tr && h->sym_dt > 0.0 && dt > 0.0 && (dt > 10.0 * h->sym_dt || dt < 0.1 * h->sym_dt) && h->sym_values_override.empty();
+        if(h->sym_class == cls && !dt_moved) return PE_HIP_OK;
+        if(tr) h->sym_dt = dt;
         auto const t0 = clk::now();
         std::vector<double> av;
         if(!h->sym_values_override.empty()) av = h->sym_values_override;
@@ -787,11 +793,19 @@ namespace
         std::vector<long long> s1(B);
         HIPCHK(h, hipMemcpy(status.data(), h->V.status, B * sizeof(int), hipMemcpyDeviceToHost));
         HIPCHK(h, hipMemcpy(s1.data(), h->V.n_steps, B * sizeof(long long), hipMemcpyDeviceToHost));
+        // a zero / non-finite pivot under the order matched at load time gets ONE re-match on the instance's own values too (a switch
+        // toggled through update_param, a parameter that moved by orders of magnitude): the reference would simply pivot elsewhere
         std::vector<int> failed;
+        bool any_inaccurate = false;
         for(int b = 0; b < B; ++b)
-            if(status[b] == PE_HIP_ERR_INACCURATE) failed.push_back(b);
+            if(status[b] == PE_HIP_ERR_INACCURATE || (status[b] == PE_HIP_ERR_SINGULAR && !h->singular_rematched))
+            {
+                failed.push_back(b);
+                any_inaccurate = any_inaccurate || status[b] == PE_HIP_ERR_INACCURATE;
+            }
         if(failed.empty() || attempt >= 2) return PE_HIP_OK;
-        if(attempt == 0 && !h->careful) h->careful = true;
+        if(!any_inaccurate) h->singular_rematched = true;  // (once per resident circuit: a structurally singular system stays singular)
+        if(any_inaccurate && attempt == 0 && !h->careful) h->careful = true;
         else
         {
             // re-match on the failing instance's own assembled values (device order = front-assembly order -> CSR slots)
@@ -800,7 +814,11 @@ namespace
             std::vector<double> tmp(nnz);
             HIPCHK(h, hipMemcpy(tmp.data(), h->V.aval + static_cast<size_t>(b) * nnz, nnz * sizeof(double), hipMemcpyDeviceToHost));
             h->sym_values_override.assign(nnz, 0.0);
-            for(size_t e = 0; e < nnz; ++e) h->sym_values_override[h->sym.asm_slot[e]] = std::fabs(tmp[e]);
+            for(size_t e = 0; e < nnz; ++e)
+            {
+                double const v = std::fabs(tmp[e]);
+                h->sym_values_override[h->sym.asm_slot[e]] = v <= 1.7976931348623157e308 ? v : 1.0;  // (a non-finite entry says nothing about magnitude)
+            }
             h->sym_class = -1;
             int const rc = ensure_symbolic(h, tr, dt);
             h->sym_values_override.clear();
@@ -973,6 +991,8 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->circ_pool.release();
     h->stats_scratch = nullptr;
     h->stats_doubles = 0;
+    h->singular_rematched = false;
+    h->sym_dt = 0.0;
     h->sym_pool.release();
     if(h->ac.eng)
     {
@@ -1211,8 +1231,7 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
             h->fact_dt = dt;
         }
     }
-    if(h->V.residual_tol > 0.0)
-        for(int attempt = 0; attempt < 2; ++attempt)
+    for(int attempt = 0; attempt < 2; ++attempt)
         {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             std::vector<std::pair<int, std::vector<int>>> groups;
@@ -1267,8 +1286,7 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     }
     else
         HIPCHK(h, pe::launch_dc_point(h->stream, h->V, mode));
-    if(h->V.residual_tol > 0.0)
-        for(int attempt = 0; attempt < 2; ++attempt)
+    for(int attempt = 0; attempt < 2; ++attempt)
         {
             HIPCHK(h, hipStreamSynchronize(h->stream));
             std::vector<std::pair<int, std::vector<int>>> groups;
