@@ -16,11 +16,14 @@
 // which describes it as rows of the device tables of include/pe_hip.h.  A netlist containing a model without that hook
 // is rejected by analyze() (returns false, message in circult::last_error) -- there is no CPU numeric path.
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <concepts>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <set>
@@ -1129,6 +1132,21 @@ namespace phy_engine
         ::phy_engine::MNA::MNA mna{};
         ::std::size_t mna_mirror_rows{2048};
 
+        // circuit.h:63-68,115-121: the reference chooses between its CPU LU and the CUDA solver per solve.  Kept for source
+        // compatibility; this engine has ONE solver (the device), so auto_select and force_cuda mean the same and force_cpu makes
+        // analyze() fail loudly (there is no CPU numeric path to fall back to).
+        enum class cuda_solve_policy : ::std::uint_fast8_t
+        {
+            auto_select,
+            force_cpu,
+            force_cuda
+        };
+        inline static constexpr ::std::size_t default_cuda_node_threshold{100000};
+        cuda_solve_policy cuda_policy{cuda_solve_policy::auto_select};
+        ::std::size_t cuda_node_threshold{default_cuda_node_threshold};
+        constexpr void set_cuda_policy(cuda_solve_policy p) noexcept { cuda_policy = p; }
+        constexpr void set_cuda_node_threshold(::std::size_t n) noexcept { cuda_node_threshold = n; }
+
         circult() = default;
         circult(circult const&) = delete;
         circult& operator=(circult const&) = delete;
@@ -1143,8 +1161,35 @@ namespace phy_engine
         ::phy_engine::analyzer::analyzer_storage_t& get_analyze_setting() noexcept { return analyzer_setting; }
         pe_hip_engine* gpu_engine() noexcept { return gpu_; }
 
-        // circuit.h:179-296
+        // circuit.h:179-296.  PHY_ENGINE_PROFILE_SOLVE=1 (circuit.h:35-58,1359-1479) prints one "[profile]" line per analyze() to
+        // stderr -- per call, not per solve_once: the whole Newton / time loop of a call runs on the device.
         bool analyze() noexcept
+        {
+            if(cuda_policy == cuda_solve_policy::force_cpu)
+            {
+                last_error = "cuda_solve_policy::force_cpu: the MI355X engine has no CPU solver";
+                return false;
+            }
+            static bool const prof = []
+            {
+                char const* v = ::std::getenv("PHY_ENGINE_PROFILE_SOLVE");
+                return v && (*v == '1' || *v == 'y' || *v == 'Y' || *v == 't' || *v == 'T');
+            }();
+            if(!prof) return analyze_impl();
+            auto const t0 = ::std::chrono::steady_clock::now();
+            last_stats = pe_hip_run_stats{};
+            bool const ok = analyze_impl();
+            double const total_ms = ::std::chrono::duration<double, ::std::milli>(::std::chrono::steady_clock::now() - t0).count();
+            pe_hip_info info{};
+            if(gpu_ && loaded_) (void)pe_hip_get_info(gpu_, &info);
+            ::std::fprintf(stderr, "[profile] n=%zu nnz=%d analysis=%u steps=%lld newton_iters=%lld hip_total_ms=%.6g (launches=%d dominant_ms=%.6g) ok=%d total_ms=%.6g\n",
+                           node_counter + branch_counter, info.nnz_a, static_cast<unsigned>(at), last_stats.steps, last_stats.newton_iters, last_stats.gpu_ms,
+                           last_stats.n_launches, last_stats.dominant_ms, ok ? 1 : 0, total_ms);
+            return ok;
+        }
+
+    private:
+        bool analyze_impl() noexcept
         {
             switch(at)
             {
@@ -1173,6 +1218,7 @@ namespace phy_engine
             }
         }
 
+    public:
         // circuit.h:70-82, 173-177
         struct ac_sweep_point
         {
