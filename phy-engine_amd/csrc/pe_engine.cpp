@@ -603,10 +603,15 @@ namespace
             double const e = den > 0.0 ? n[0] / den : (n[0] > 0.0 ? INFINITY : 0.0);
             return !(e <= h->V.residual_tol);
         };
+        // only iterates about to be accepted were checked on the device (k_m2_residual): nothing to read while every active instance
+        // still shows a Newton violation
+        bool any = false;
+        for(int b = 0; b < B && !any; ++b) any = S.active[b] && !(S.flags[b] & 5) && !(h->hc.nonlinear && (S.flags[b] & 2));
+        if(!any) return PE_HIP_OK;
         if(int const rc = pull_eta(); rc != PE_HIP_OK) return rc;
         std::vector<int> todo;
         for(int b = 0; b < B; ++b)
-            if(S.active[b] && !(S.flags[b] & 5) && bad(b)) todo.push_back(b);
+            if(S.active[b] && !(S.flags[b] & 5) && !(h->hc.nonlinear && (S.flags[b] & 2)) && bad(b)) todo.push_back(b);
         if(todo.empty()) return PE_HIP_OK;
         std::vector<int> mask(B);
         for(int round = 0; round < 2 && !todo.empty(); ++round)
