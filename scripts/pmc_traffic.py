@@ -43,3 +43,19 @@ out = {
 out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
 json.dump(out, open(os.path.join(root, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+
+
+def slim(d, counter, dst):
+    """profiles/r02_pmc_<counter>.csv: the engine's kernels only, the columns the summary uses."""
+    cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(dst, "w", newline="") as o:
+        wr = csv.writer(o)
+        wr.writerow(cols)
+        for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+            for row in csv.DictReader(open(f)):
+                if "pe::k_" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    wr.writerow([row[c] for c in cols])
+
+
+slim(fetch_dir, "FETCH_SIZE", os.path.join(root, "profiles", "r02_pmc_FETCH_SIZE.csv"))
+slim(write_dir, "WRITE_SIZE", os.path.join(root, "profiles", "r02_pmc_WRITE_SIZE.csv"))
