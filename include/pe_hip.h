@@ -251,7 +251,8 @@ int pe_hip_get_matrix(pe_hip_engine* h, int instance, int* row_ptr, int* col_ind
  * the factor-reuse path is counted here too), [6] cooperative assembly, [7] cooperative block loops */
 int pe_hip_get_phase_clocks(pe_hip_engine* h, int instance, long long* ticks8);
 /* the same plus, from slot 8 on, six values per cooperative-front layout (0 whole front in LDS, 1 pivot panels + pulled Schur
- * tiles, 2 chain link): assembly, block loop, Schur update, factor store [ticks], fronts [count], sum of m*m */
+ * tiles, 2 chain link): assembly, block loop, Schur update, factor store [ticks], fronts [count], sum of m*m; slots 48.. (split
+ * schedule): for parts 0..3 of the instance, start / end tick and hardware placement of that workgroup in the last factor launch */
 int pe_hip_get_phase_clocks_ex(pe_hip_engine* h, int instance, int capacity, long long* ticks, int* n_out);
 
 /* host-only: run the symbolic analysis on a pattern and report its statistics (no GPU needed) */

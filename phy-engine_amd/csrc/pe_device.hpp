@@ -18,7 +18,7 @@ namespace pe
     // wavefronts 0..5 of part 0; [32..38] the same six figures (+ own-entries share of the assembly) for the wave fronts of wavefront 0 of part 0; [40..47] factorisation time of parts 0..7
     enum : int
     {
-        PE_PROF = 48
+        PE_PROF = 64
     };
 
     // diode parameter columns after host-side prepare_foundation (PN_junction.h:296-354)

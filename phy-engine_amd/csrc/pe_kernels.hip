@@ -654,7 +654,17 @@ namespace pe
         int const b = static_cast<int>(blockIdx.x);
         if(!V.active[b]) return;
         HipTeam tm;
+        long long const t_start = V.prof ? tm.clock() : 0;
         if(!factor_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds, true) && tm.tid() == 0) atomicOr(V.flags + b, 4);
+        // developer timeline (scripts/wg_timeline.py): start / end (100 MHz wall clock) and placement of the workgroups of parts 0..3 in
+        // the LAST launch -- XCC_ID in the high word, HW_ID (wave slot, SIMD, CU, SE) in the low word
+        if(V.prof && tm.tid() == 0 && blockIdx.y < 4)
+        {
+            long long* q = V.prof + b * PE_PROF + 48 + 3 * static_cast<int>(blockIdx.y);
+            q[0] = t_start;
+            q[1] = tm.clock();
+            q[2] = (static_cast<long long>(__builtin_amdgcn_s_getreg(6164)) << 32) | static_cast<unsigned>(__builtin_amdgcn_s_getreg(63492));
+        }
     }
 
     template <int MINW>
