@@ -209,6 +209,9 @@ namespace
         V.residual_tol = o.residual_tol < 0.0 ? 0.0 : (o.residual_tol > 0.0 ? o.residual_tol : 1e-10);
     }
 
+    // pe_hip_sweep_statistics: instance chunks of the first pass -- enough workgroups to stream x at HBM rate, few enough for a cheap second pass
+    int stats_chunks(int batch) { return std::clamp(batch / 32, 1, 64); }
+
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
     // test knob: choose the launch geometry as if the batch had this many instances
     int geometry_batch(int batch)
@@ -1087,6 +1090,13 @@ int finish_load(pe_hip_engine* h)
     HIPCHK(h, P.alloc(V.trace, static_cast<size_t>(V.trace_cap)));
     HIPCHK(h, P.alloc(V.trace_len, 1));
     HIPCHK(h, P.alloc(V.prof, B * pe::PE_PROF));
+    {
+        // scratch of pe_hip_sweep_statistics, allocated with the circuit: a first-call hipMalloc costs milliseconds (7.6 ms measured
+        // at 128 instances), the statistics themselves 0.05-0.1 ms
+        size_t const need = static_cast<size_t>(stats_chunks(static_cast<int>(B)) + 1) * 4 * hc.rows;
+        HIPCHK(h, P.alloc(h->stats_scratch, need, false));
+        h->stats_doubles = need;
+    }
     HIPCHK(h, P.alloc(V.active, B));
     HIPCHK(h, P.alloc(V.flags, B));
     // residual safety net: CSR of A in original order (shared) + per-instance refinement buffers
@@ -1397,7 +1407,7 @@ int pe_hip_sweep_statistics(pe_hip_engine* h, double* out)
     HIPCHK(h, hipSetDevice(h->device));
     int const rows = h->hc.rows, B = h->hc.batch;
     if(rows == 0) return PE_HIP_OK;
-    int const n_chunks = std::clamp(B / 32, 1, 64);  // enough workgroups to stream x at HBM rate, few enough for a cheap second pass
+    int const n_chunks = stats_chunks(B);
     size_t const need = static_cast<size_t>(n_chunks + 1) * 4 * rows;
     if(h->stats_doubles < need)  // scratch kept with the resident circuit (an allocation per call would cost more than the kernels)
     {
