@@ -705,6 +705,24 @@ namespace pe
         }
     }
 
+    // ... and with 8: a level of 257..512 workgroups fills half of the wavefront slots with 4-wavefront workgroups; two 8-wavefront
+    // workgroups per CU use all of them (128 instances x 4 fronts: the lower top levels of the 8-GPU share of the sweep)
+    __global__ void __launch_bounds__(512, 4) k_m2_factor_top_mid(DevView V, int level, int nlev)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        for(int l = level; l < level + nlev; ++l)
+        {
+            int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
+            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            {
+                if(tm.tid() == 0) atomicOr(V.flags + b, 4);
+                return;
+            }
+        }
+    }
+
     __global__ void __launch_bounds__(256) k_m2_winit(DevView V)
     {
         int const b = static_cast<int>(blockIdx.y);
@@ -899,6 +917,7 @@ namespace pe
             hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_wide), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_mid), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts<MINW>), lds_s);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_s);
             if(e != hipSuccess) return e;
@@ -939,7 +958,11 @@ namespace pe
                 // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
                 // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %)
                 bool const wide = wide_knob && (MINW == 2 || V.top_cnt[l] * B <= 320);
+                static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
+                bool const mid = !wide && MINW == 4 && T == 256 && V.top_cnt[l] * B <= mid_knob;
                 if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), lds, st, V, l, run(l));
+                else if(mid)
+                    hipLaunchKernelGGL(k_m2_factor_top_mid, dim3(V.top_cnt[l], B), dim3(512), lds, st, V, l, run(l));
                 else
                     hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
             }
