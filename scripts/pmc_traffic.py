@@ -13,9 +13,15 @@ line = json.loads(open(bench_json).read().strip().splitlines()[-1])
 kernel = sys.argv[4] if len(sys.argv) > 4 else line["roofline"]["kernel"].split("<")[0]
 
 
+def newest(d):
+    """gpurun merges every call's output into gpurun_out/: only the newest pass of a directory counts."""
+    fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
 def total(d, counter):
     s, n = 0.0, 0
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(d):
         for row in csv.DictReader(open(f)):
             if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
                 s += float(row["Counter_Value"])
@@ -51,7 +57,7 @@ def slim(d, counter, dst):
     with open(dst, "w", newline="") as o:
         wr = csv.writer(o)
         wr.writerow(cols)
-        for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
+        for f in newest(d):
             for row in csv.DictReader(open(f)):
                 if "pe::k_" in row["Kernel_Name"] and row["Counter_Name"] == counter:
                     wr.writerow([row[c] for c in cols])
