@@ -96,6 +96,12 @@ struct pe_hip_engine
     bool singular_rematched{};    // the one re-match after a singular pivot has been spent for this resident circuit
     bool careful{};               // residual safety net tripped on the resident kernel: stay on the host-driven (refining) schedule
     long long n_refined{}, n_rematched{};  // solves repaired by refinement / symbolic re-analyses on an instance's own values (diagnostics)
+    // host-driven Newton loop (split schedule): pinned staging for the per-iteration `active` upload / `flags` read-back, and what
+    // the device's `active` array currently holds (an unchanged mask is not uploaded again)
+    int* pin_active{};
+    int* pin_flags{};
+    size_t pin_cap{};
+    std::vector<int> active_dev;
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
     size_t stats_doubles{};
     Pool circ_pool;  // topology, params, state
@@ -586,6 +592,39 @@ namespace
         return PE_HIP_OK;
     }
 
+    int ensure_pinned(pe_hip_engine* h, size_t n)
+    {
+        if(h->pin_cap >= n) return PE_HIP_OK;
+        if(h->pin_active) (void)hipHostFree(h->pin_active);
+        if(h->pin_flags) (void)hipHostFree(h->pin_flags);
+        h->pin_active = h->pin_flags = nullptr;
+        h->pin_cap = 0;
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_active), n * sizeof(int), hipHostMallocDefault));
+        HIPCHK(h, hipHostMalloc(reinterpret_cast<void**>(&h->pin_flags), n * sizeof(int), hipHostMallocDefault));
+        h->pin_cap = n;
+        return PE_HIP_OK;
+    }
+    // `active` mask of the next launches (stream-ordered).  The caller synchronises the stream before it changes the mask again,
+    // so the one pinned staging buffer is free by then.
+    int upload_active(pe_hip_engine* h, std::vector<int> const& mask)
+    {
+        if(h->active_dev == mask) return PE_HIP_OK;
+        if(int const rc = ensure_pinned(h, mask.size()); rc != PE_HIP_OK) return rc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // (an earlier upload from the staging buffer may still be in flight)
+        std::copy(mask.begin(), mask.end(), h->pin_active);
+        HIPCHK(h, hipMemcpyAsync(h->V.active, h->pin_active, mask.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        h->active_dev = mask;
+        return PE_HIP_OK;
+    }
+    int download_flags(pe_hip_engine* h, std::vector<int>& flags)
+    {
+        if(int const rc = ensure_pinned(h, flags.size()); rc != PE_HIP_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->pin_flags, h->V.flags, flags.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::copy(h->pin_flags, h->pin_flags + flags.size(), flags.begin());
+        return PE_HIP_OK;
+    }
+
     // Residual safety net on the host-driven schedule.  The iteration just launched left the four norms of every active instance's
     // solve in eta_acc.  Instances above the tolerance get up to two rounds of iterative refinement (launch_m2_refine: active =
     // exactly those); their flags are then the Newton / finiteness bits of the corrected x.  What refinement cannot repair leaves
@@ -621,7 +660,7 @@ namespace
         {
             std::fill(mask.begin(), mask.end(), 0);
             for(int b: todo) mask[b] = 1;
-            HIPCHK(h, hipMemcpyAsync(h->V.active, mask.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            if(int const urc = upload_active(h, mask); urc != PE_HIP_OK) return urc;
             HIPCHK(h, pe::launch_m2_refine(h->stream, h->V));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if(int const rc = pull_eta(); rc != PE_HIP_OK) return rc;
@@ -662,11 +701,10 @@ namespace
         {
             if(has_overlay(h))
                 if(int const rc = overlay_call(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step); rc != PE_HIP_OK) return rc;
-            HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1));
             ++launches;
-            HIPCHK(h, hipMemcpyAsync(S.flags.data(), h->V.flags, B * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK) return drc;  // (synchronises the stream)
             {
                 float kms = 0.f;
                 if(hipEventElapsedTime(&kms, h->evk0, h->evk1) == hipSuccess)
@@ -723,7 +761,7 @@ namespace
                     if(!(*only)[b] && S.status[b] == PE_HIP_OK) S.status[b] = -1000;
             if(has_overlay(h) && !(only && s == 0))
                 if(int const orc = overlay_call(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt); orc != PE_HIP_OK) return orc;
-            HIPCHK(h, hipMemcpyAsync(h->V.active, S.active.data(), B * sizeof(int), hipMemcpyHostToDevice, h->stream));
+            if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             if(!(only && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
             double t_prev = 0.0;
@@ -907,6 +945,8 @@ void pe_hip_destroy(pe_hip_engine* h)
     (void)hipEventDestroy(h->evk0);
     (void)hipEventDestroy(h->evk1);
     (void)hipStreamDestroy(h->stream);
+    if(h->pin_active) (void)hipHostFree(h->pin_active);
+    if(h->pin_flags) (void)hipHostFree(h->pin_flags);
     delete h;
 }
 
@@ -999,6 +1039,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->circ_pool.release();
     h->stats_scratch = nullptr;
     h->stats_doubles = 0;
+    h->active_dev.clear();
     h->singular_rematched = false;
     h->sym_dt = 0.0;
     h->sym_pool.release();

@@ -22,6 +22,9 @@ inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+constexpr unsigned hipHostMallocDefault = 0;
+inline hipError_t hipHostMalloc(void** p, size_t b, unsigned) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t b) { std::memset(p, v, b); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t b, hipStream_t) { std::memset(p, v, b); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t b, hipMemcpyKind) { std::memcpy(d, s, b); return hipSuccess; }
