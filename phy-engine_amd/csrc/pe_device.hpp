@@ -129,6 +129,8 @@ namespace pe
         int lds_wave_stage{}, lds_coop_stage{};  // doubles of the staged block of a wavefront / of the workgroup in the triangular solves
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
         int lds_solve_doubles;  // ... of the triangular-solve kernels of the split schedule
+        // lean plan of the backward pass (front_backward_lean: only U11 staged): slot, stack offset, staged block, launch size
+        int lds_sslot_b{}, lds_bstack_off_b{}, lds_wave_stage_b{}, lds_solve_b_doubles{};
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;
         int max_newton;

@@ -272,6 +272,9 @@ namespace
         V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
         V.lds_bstack_off = so.wave_m + V.lds_wave_stage + 64;  // t[m] + staged block + partial sums of one wavefront,
         V.lds_sslot = V.lds_bstack_off + std::max(1, S.wave_stack);  // + the backward stack (the solved vectors along one path of a wave subtree)
+        V.lds_wave_stage_b = so.wave_p * so.wave_p;            // backward pass: U11 only (front_backward_lean)
+        V.lds_bstack_off_b = so.wave_m + V.lds_wave_stage_b + 64;
+        V.lds_sslot_b = V.lds_bstack_off_b + std::max(1, S.wave_stack);
         {
             long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
             need = std::max(need, so.panel_doubles + so.panel_reserve);
@@ -282,6 +285,8 @@ namespace
             long long const need_solve = std::max(static_cast<long long>(so.n_waves) * V.lds_sslot,
                                                   static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
             V.lds_solve_doubles = static_cast<int>(need_solve + 2);
+            V.lds_solve_b_doubles = static_cast<int>(std::max(static_cast<long long>(so.n_waves) * V.lds_sslot_b,
+                                                              static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64) + 2);
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
@@ -463,6 +468,9 @@ namespace
         h->sym_pool.release();
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
+        if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
+            std::fprintf(stderr, "[pe_hip]   LDS plan (doubles): factor %d, solves %d, backward %d (wave slot %d = t %d + stage %d + 64 + stack %d), wave front slot %d\n", h->V.lds_doubles,
+                         h->V.lds_solve_doubles, h->V.lds_solve_b_doubles, h->V.lds_sslot, h->V.wave_m, h->V.lds_wave_stage, h->V.lds_sslot - h->V.lds_bstack_off, h->V.lds_slot);
         {
             // The matrix values live in FRONT-ASSEMBLY order on the device: slot e of `aval` is the e-th assembled entry
             // (asm_slot is a permutation of the CSR slots), so a front reads its own entries of A as one contiguous run with no

@@ -1188,6 +1188,107 @@ namespace pe
         for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
     }
 
+    // The same step with a LEAN LDS plan (split schedule: the backward launch then fits 8 workgroups per CU instead of 6, and
+    // its 4 096 workgroups run in two rounds instead of three): only U11 (p x p) is staged; the product U12 * x_U reads U12
+    // straight from HBM, spread over ALL lanes of the team -- lane -> (row i = lane mod R, column group jg = lane / R), each
+    // lane accumulating the columns j = jg, jg + G, ... (G groups of R >= p lanes; 128-byte segments per quarter-wave), the G
+    // partial sums per row meet in LDS.  Requires p <= R; columns beyond the first 9 per lane are fetched in further rounds
+    // (never on the 64-lane teams the geometry produces: u <= 36).
+    template <class Team>
+    PE_DEV void front_backward_lean(Team const& tm, DevView const& V, int b, int s_in, double* sc)
+    {
+        int const s = tm.uniform(s_in);
+        int const c0 = V.f_col0[s], p = V.f_p[s], u = V.f_u[s], m = p + u;
+        int const T = tm.size(), t0 = tm.tid();
+        double* w = V.w + static_cast<long long>(b) * V.rows;
+        double const* fac = V.factor + static_cast<long long>(b) * V.factor_doubles;
+        double const* Lg = fac + V.f_lptr[s];
+        double const* Ug = fac + V.f_uptr[s];
+        int const par = V.f_wpar[s];
+        double* stack = sc + V.lds_bstack_off_b;
+        double* t = stack + V.f_wstack[s];           // [m]: this front's solved vector, read by its children
+        double* Ub = sc + V.wave_m;                  // staged U11 [p x p, ld p]
+        double* part = Ub + V.lds_wave_stage_b;      // [T] partial sums of U12 * x_U
+        // lane -> (row, column group)
+        int const R = T >= 64 ? (p <= 16 ? 16 : (p <= 32 ? 32 : 64)) : 1;
+        int const G = T / R;
+        int const row = t0 % R, jg = t0 / R;
+        constexpr int UQ = 9;
+        int const nq = (u + G - 1) / G;              // columns per lane
+        // global loads first: they depend on nothing in LDS
+        double ug[UQ];
+        {
+            int const i = row < p ? row : p - 1;
+#pragma unroll
+            for(int q = 0; q < UQ; ++q)
+            {
+                int const j = jg + G * q;
+                ug[q] = (u > 0) ? Ug[i + static_cast<long long>(j < u ? j : u - 1) * p] : 0.0;
+            }
+        }
+        if(par < 0)
+        {
+            int const* rows = V.f_rows + V.f_rows_ptr[s];
+            for(int j = t0; j < u; j += T) t[p + j] = w[rows[j]];
+        }
+        else
+        {
+            int const* rel = V.f_rel + V.f_rows_ptr[s];
+            double const* tp = stack + par;
+            for(int j = t0; j < u; j += T) t[p + j] = tp[rel[j]];
+        }
+        {
+            float const rp = 1.0f / static_cast<float>(p);
+            for(int idx = t0; idx < p * p; idx += T)
+            {
+                int const k = fdiv(idx, rp), i = idx - k * p;
+                Ub[idx] = Lg[i + k * m];
+            }
+        }
+        double const wi = t0 < p ? w[c0 + t0] : 0.0;
+        tm.sync_lds();
+        for(int i = row; i < p; i += R)  // (one pass on a 64-lane team; the serial emulation walks the rows)
+        {
+            double acc = 0.0;
+            if(i == row && row < p)
+            {
+#pragma unroll
+                for(int q = 0; q < UQ; ++q)
+                {
+                    int const j = jg + G * q;
+                    if(q < nq && j < u) acc += ug[q] * t[p + j];
+                }
+            }
+            else
+                for(int q = 0; q < (nq < UQ ? nq : UQ); ++q)
+                {
+                    int const j = jg + G * q;
+                    if(j < u) acc += Ug[i + static_cast<long long>(j) * p] * t[p + j];
+                }
+            for(int q = UQ; q < nq; ++q)
+            {
+                int const j = jg + G * q;
+                if(j < u) acc += Ug[i + static_cast<long long>(j) * p] * t[p + j];
+            }
+            part[jg * R + i] = acc;
+        }
+        tm.sync_lds();
+        for(int i = t0; i < p; i += T)
+        {
+            double acc = i == t0 ? wi : w[c0 + i];
+            for(int g2 = 0; g2 < G; ++g2) acc -= part[g2 * R + i];
+            t[i] = acc;
+        }
+        tm.sync_lds();
+        tm.for_each_wave(
+            [&](int wv, int lane, int)
+            {
+                if(wv == 0) tm.tri_upper(t, Ub, p, p, 0, lane);
+            });
+        tm.sync_lds();
+        for(int i = t0; i < p; i += T) w[c0 + i] = t[i];
+    }
+
     template <class Team>
     PE_DEV void forward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
@@ -1216,20 +1317,20 @@ namespace pe
             [&](int wv, int lane, int NL)
             {
                 auto wt = tm.wave_team(lane);
-                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot;
+                double* sc = lds + static_cast<long long>(wv) * V.lds_sslot_b;
                 int const q0 = tm.uniform(wp[wv]);
                 for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q)
                 {
                     int const sq = tm.uniform(V.wave_list[q]);
                     int const pq = V.f_p[sq], mq = pq + V.f_u[sq];
-                    // (every wave front fits the staging block by construction; the general routine stays as the fallback, followed
-                    // by the gather that puts its solved vector on the stack for the children)
-                    if(mq <= 64 && mq <= V.wave_m && mq * pq <= V.lds_wave_stage) front_backward_stacked(wt, V, b, sq, sc);
+                    // (every wave front qualifies by construction; the general routine stays as the fallback, followed by the gather
+                    // that puts its solved vector on the stack for the children)
+                    if(pq <= 64 && mq <= V.wave_m && pq * pq <= V.lds_wave_stage_b) front_backward_lean(wt, V, b, sq, sc);
                     else
                     {
-                        front_backward(wt, V, b, sq, sc, V.wave_m, V.lds_wave_stage);
+                        front_backward(wt, V, b, sq, sc, V.wave_m, V.lds_wave_stage_b);
                         double const* wb = V.w + static_cast<long long>(b) * V.rows;
-                        double* tq = sc + V.lds_bstack_off + V.f_wstack[sq];
+                        double* tq = sc + V.lds_bstack_off_b + V.f_wstack[sq];
                         int const* rows = V.f_rows + V.f_rows_ptr[sq];
                         for(int i = wt.tid(); i < mq; i += wt.size()) tq[i] = i < pq ? wb[V.f_col0[sq] + i] : wb[rows[i - pq]];
                         wt.sync_lds();

@@ -744,6 +744,16 @@ namespace pe
             forward_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds);
     }
 
+    // the backward pass of the parts for 4-wavefront workgroups at 8 wavefronts per SIMD (64 VGPRs, lean LDS plan of
+    // front_backward_lean): 8 workgroups per CU, i.e. the 4 096 workgroups of the 1 024-instance sweep in two rounds
+    __global__ void __launch_bounds__(256, 8) k_m2_backward_parts(DevView V)
+    {
+        int const b = static_cast<int>(blockIdx.x);
+        if(!V.active[b]) return;
+        HipTeam tm;
+        backward_part(tm, V, b, static_cast<int>(blockIdx.y), pe_lds);
+    }
+
     template <int MINW>
     __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_solve_top(DevView V, int level, int nlev, int backward)
     {
@@ -979,7 +989,16 @@ namespace pe
             l -= n;
         }
         if(!do_factor && ev0) (void)hipEventRecord(ev0, st);
-        hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 1);
+        // (the backward pass of the parts runs on the lean LDS plan: more workgroups per CU)
+        size_t const lds_b = static_cast<size_t>(V.lds_solve_b_doubles) * sizeof(double);
+        if(T <= 256)
+        {
+            hipError_t const e = set_lds(reinterpret_cast<void const*>(&k_m2_backward_parts), lds_b);
+            if(e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_m2_backward_parts, dim3(B, V.n_parts), dim3(T), lds_b, st, V);
+        }
+        else
+            hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_b, st, V, 1);
         if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
         if(!refine)
         {
