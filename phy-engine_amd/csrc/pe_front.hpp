@@ -397,11 +397,10 @@ namespace pe
     // ------------------------------------------------------------------------------------------------
     // out[s] = sum over the contribution list of slot s, in list order; four slots per thread in flight (the three
     // dependent loads ptr -> src -> dv of one slot would otherwise be fully exposed)
-    template <class Team>
-    PE_DEV void gather_contributions(Team const& tm, int const* ptr, int const* src, double const* dv, double* out, int n)
+    // (t0, T): this thread's index and the thread count of the group that shares the slot range [lo, hi)
+    PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n)
     {
-        int const T = tm.size();
-        for(int base = tm.tid(); base < n; base += 4 * T)
+        for(int base = lo + t0; base < n; base += 4 * T)
         {
             int e[4], end[4];
             double acc[4];
@@ -443,8 +442,26 @@ namespace pe
     PE_DEV void stamp(Team const& tm, DevView const& V, int b)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
-        gather_contributions(tm, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, V.nnzA);
-        gather_contributions(tm, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, V.rows);
+        gather_contributions(tm.tid(), tm.size(), V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, 0, V.nnzA);
+        gather_contributions(tm.tid(), tm.size(), V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, 0, V.rows);
+    }
+    // the same with the slots dealt out in CONTIGUOUS chunks to G groups of T threads (split schedule: one workgroup per chunk).
+    // The matrix slots are in front-assembly order, so a chunk is a patch of the circuit and the device values it gathers are
+    // few enough to stay in the CU's L1: a 64-byte sector of dv is fetched from L2 once per chunk instead of once per lane.
+    PE_DEV void stamp_chunk(DevView const& V, int b, int g, int G, int t0, int T)
+    {
+        double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
+        auto range = [&](int n, int& lo, int& hi)
+        {
+            int const c = (n + G - 1) / G;
+            lo = g * c < n ? g * c : n;
+            hi = lo + c < n ? lo + c : n;
+        };
+        int lo, hi;
+        range(V.nnzA, lo, hi);
+        gather_contributions(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi);
+        range(V.rows, lo, hi);
+        gather_contributions(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi);
     }
 
     // ================================================================================================

@@ -641,7 +641,7 @@ namespace pe
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
-        stamp(GridTeam{}, V, b);
+        stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     }
 
     // (the four team kernels of the split schedule come in the two register budgets of the resident kernels: MINW = 2 for few
