@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pe_load
 pe = pe_load.load()
-TOTAL, STEPS = 1024, int(os.environ.get("STEPS", "20"))
+TOTAL, STEPS = int(os.environ.get("TOTAL", "1024")), int(os.environ.get("STEPS", "20"))
 for G in [int(x) for x in os.environ.get("GROUPS", "1,2,4").split(",")]:
     per = TOTAL // G
     engs = []
