@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include "pe_symbolic.hpp"  // pe_ld
+
 namespace pe
 {
     // dv ("device values") is the per-instance vector every matrix / RHS contribution is gathered from.

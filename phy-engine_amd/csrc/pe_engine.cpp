@@ -267,7 +267,7 @@ namespace
         V.max_m = std::max(S.max_m, 1);
         V.max_p = so.max_pivots;
         V.wave_p = so.wave_p;
-        V.lds_slot = so.wave_m * (so.wave_m + 1);  // a wavefront's slot holds its fronts whole (order <= wave_m) + the right-hand-side column
+        V.lds_slot = (pe::pe_ld(so.wave_m) + 1) * so.wave_m;  // a wavefront's slot holds its fronts whole (order <= wave_m, odd leading dimension) + the right-hand-side column
         V.lds_wave_stage = so.wave_m * so.wave_p;              // a wavefront stages the whole m x p panel of its (small) fronts
         V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
         V.lds_bstack_off = so.wave_m + V.lds_wave_stage + 64;  // t[m] + staged block + partial sums of one wavefront,
@@ -373,7 +373,7 @@ namespace
         so.shared_cu = (resident > 1) ? 1 : 0;
         long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
         // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
-        while(static_cast<long long>(so.n_waves) * so.wave_m * (so.wave_m + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
+        while(static_cast<long long>(so.n_waves) * so.wave_m * (pe::pe_ld(so.wave_m) + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
         so.wave_p = std::min(so.wave_p, so.wave_m);
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
         // large (panel-mode) fronts keep room behind the panels for the right-hand-side column (m doubles) and their

@@ -533,13 +533,14 @@ namespace pe
         int const mode = tm.uniform(V.f_mode[s]);  // fixed with the launch geometry (build_assembly_lists): same rule, one place
         bool const full = mode == 0;
         bool const chain = mode == 2;  // the single child's update matrix IS this front: f_rel of the child is the identity
-        int const ldu = full ? m : p;
-        int const nlds = full ? m * m : m * p + p * u;
+        int const ldl = pe_ld(m);               // LDS leading dimension of the L panel / of the whole image (odd: bank spread)
+        int const ldu = full ? ldl : pe_ld(p);  // ... of the U panel
+        int const nlds = full ? ldl * m : ldl * p + ldu * u;
 #if !defined(__HIPCC__)
         assert(nlds + (fuse ? m : 0) <= cap && "front image + right-hand-side column overrun the team's LDS region");
 #endif
         double* Lp = lds;
-        double* Up = lds + m * p;
+        double* Up = lds + ldl * p;
         double* g = lds + nlds;  // [m] right-hand-side column (fuse)
         int const T = tm.size(), t0 = tm.tid();
         int const c0 = V.f_col0[s];
@@ -564,7 +565,7 @@ namespace pe
         auto place = [&](int pos, double v)
         {
             int const r = pos >> 16, c = pos & 0xffff;
-            if(c < p) Lp[r + c * m] += v;
+            if(c < p) Lp[r + c * ldl] += v;
             else
                 Up[r + (c - p) * ldu] += v;  // r < p: an entry of A owned by this front touches a pivot row or column
         };
@@ -581,6 +582,7 @@ namespace pe
             // the child's update matrix IS this front (a long separator split into links): straight copies
             int const c = V.f_child[ch0];
             double const* Sc = arena + V.f_sptr[c];
+            float const rm = 1.0f / static_cast<float>(m);
             for(int base = t0; base < m * p; base += 4 * T)
             {
                 double v[4];
@@ -588,7 +590,11 @@ namespace pe
                 for(int q = 0; q < 4; ++q) v[q] = Sc[base + q * T < m * p ? base + q * T : 0];
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
-                    if(base + q * T < m * p) Lp[base + q * T] += v[q];
+                    if(base + q * T < m * p)
+                    {
+                        int const idx = base + q * T, cc = fdiv(idx, rm), r = idx - cc * m;
+                        Lp[r + cc * ldl] += v[q];
+                    }
             }
             float const rp = 1.0f / static_cast<float>(p);
             for(int base = t0; base < p * u; base += 4 * T)
@@ -604,7 +610,11 @@ namespace pe
                 }
 #pragma unroll
                 for(int q = 0; q < 4; ++q)
-                    if(base + q * T < p * u) Up[base + q * T] += v[q];
+                    if(base + q * T < p * u)
+                    {
+                        int const idx = base + q * T, cc = fdiv(idx, rp), r = idx - cc * p;
+                        Up[r + cc * ldu] += v[q];
+                    }
             }
             if(fuse)
             {
@@ -686,7 +696,7 @@ namespace pe
             {
                 // one wavefront owns the front (m <= 64): diagonal block, rows below it and columns right of it in ONE pass over
                 // registers, cross-lane traffic on v_readlane (tm.block_step)
-                tm.for_each_wave([&](int, int lane, int) { bad |= tm.block_step(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, lane); });
+                tm.for_each_wave([&](int, int lane, int) { bad |= tm.block_step(Lp, ldl, m, Up, ldu, g, p, u, k0, kb, fuse, lane); });
             }
             else
             {
@@ -694,11 +704,11 @@ namespace pe
                 tm.for_each_wave(
                     [&](int w, int lane, int NL)
                     {
-                        if(w == 0) bad |= tm.diag_lu8(Lp + k0 + k0 * m, m, kb, lane);
+                        if(w == 0) bad |= tm.diag_lu8(Lp + k0 + k0 * ldl, ldl, kb, lane);
                     });
                 tm.sync_lds();
                 // (a1) rows below the block (L) and columns right of it (U): one thread each (tm.panel_solve)
-                tm.panel_solve(Lp, m, Up, ldu, g, p, u, k0, kb, fuse, t0, T);
+                tm.panel_solve(Lp, ldl, m, Up, ldu, g, p, u, k0, kb, fuse, t0, T);
             }
             tm.sync_lds();
             // (b) trailing update of both panels, one 16 x 16 tile per wavefront at a time
@@ -710,7 +720,7 @@ namespace pe
                         double acc = g[r];
 #pragma unroll
                         for(int kk = 0; kk < NB; ++kk)
-                            if(kk < kb) acc -= Lp[r + (k0 + kk) * m] * g[k0 + kk];
+                            if(kk < kb) acc -= Lp[r + (k0 + kk) * ldl] * g[k0 + kk];
                         g[r] = acc;
                     }
                 int const trL = (m - r0 + 15) / 16, tcL = (p - r0 + 15) / 16;   // L panel: rows r0..m, cols r0..p
@@ -729,10 +739,10 @@ namespace pe
                                 int const tc = tile / trL, tr = tile - tc * trL;
                                 row0 = r0 + 16 * tr;
                                 int const col0 = r0 + 16 * tc;
-                                C = Lp + row0 + col0 * m;
-                                ldc = m;
-                                B = Lp + k0 + col0 * m;
-                                ldb = m;
+                                C = Lp + row0 + col0 * ldl;
+                                ldc = ldl;
+                                B = Lp + k0 + col0 * ldl;
+                                ldb = ldl;
                                 mr = m - row0 < 16 ? m - row0 : 16;
                                 nc = p - col0 < 16 ? p - col0 : 16;
                             }
@@ -750,7 +760,7 @@ namespace pe
                                 nc = u - col0 < 16 ? u - col0 : 16;
                             }
                             auto acc = tm.tile_load(C, ldc, mr, nc, lane);
-                            tm.tile_mulsub(acc, Lp + row0 + k0 * m, m, B, ldb, mr, nc, kb, lane);
+                            tm.tile_mulsub(acc, Lp + row0 + k0 * ldl, ldl, B, ldb, mr, nc, kb, lane);
                             tm.tile_store(acc, C, ldc, mr, nc, lane);
                         }
                     });
@@ -864,7 +874,7 @@ namespace pe
                             auto rest = rest_next;
                             if(tile + NW < nt * nt) rest_next = first_two(tile + NW, n0, n1);
                             auto acc = tm.tile_zero();
-                            tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
+                            tm.tile_mulsub(acc, Lp + p + i0, ldl, Up + j0 * ldu, ldu, mr, nc, p, lane);
                             tm.tile_add(acc, raw0);
                             tm.tile_add(acc, raw1);
                             while(rest)
@@ -910,7 +920,7 @@ namespace pe
                                 }
                             }
                         }
-                        tm.tile_mulsub(acc, Lp + p + i0, m, Up + j0 * ldu, ldu, mr, nc, p, lane);
+                        tm.tile_mulsub(acc, Lp + p + i0, ldl, Up + j0 * ldu, ldu, mr, nc, p, lane);
                         tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
                     }
                 });
@@ -934,13 +944,18 @@ namespace pe
             for(int idx = t0; idx < p * p; idx += T)
             {
                 int const k = fdiv(idx, rpp), i = idx - k * p;
-                Lg[i + k * m] = Lp[i + k * m];
+                Lg[i + k * m] = Lp[i + k * ldl];
             }
         }
         if(full)
         {
+            float const rm = 1.0f / static_cast<float>(m);
             if(need_l21)
-                for(int i = t0; i < m * p; i += T) Lg[i] = lds[i];
+                for(int idx = t0; idx < m * p; idx += T)
+                {
+                    int const k = fdiv(idx, rm), i = idx - k * m;
+                    Lg[idx] = Lp[i + k * ldl];
+                }
             float const rp = 1.0f / static_cast<float>(p);
             for(int idx = t0; idx < p * u; idx += T)
             {
@@ -949,7 +964,21 @@ namespace pe
             }
         }
         else
-            for(int i = t0 + (need_l21 ? 0 : m * p); i < m * p + p * u; i += T) Lg[i] = lds[i];  // U panel follows the L panel in the factor store too
+        {
+            // (the panels sit in LDS with odd leading dimensions, in the factor store densely: U panel behind the L panel)
+            float const rm = 1.0f / static_cast<float>(m), rp = 1.0f / static_cast<float>(p);
+            if(need_l21)
+                for(int idx = t0; idx < m * p; idx += T)
+                {
+                    int const k = fdiv(idx, rm), i = idx - k * m;
+                    Lg[idx] = Lp[i + k * ldl];
+                }
+            for(int idx = t0; idx < p * u; idx += T)
+            {
+                int const j = fdiv(idx, rp), r = idx - j * p;
+                Lg[m * p + idx] = Up[r + j * ldu];
+            }
+        }
         tm.sync_lds();  // the stores drain behind the next front's loads; readers of S / the panels sit behind a full sync()
         PE_MARK("end");
         if(profile && V.prof && t0 == 0)

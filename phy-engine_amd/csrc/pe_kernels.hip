@@ -121,11 +121,11 @@ namespace pe
         // block read through v_readlane from one entry per lane.  The split between rows and columns falls on a wavefront
         // boundary (a wavefront solves rows OR columns: no divergent double pass); KB is a compile-time constant.
         template <int KB>
-        __device__ __forceinline__ void panel_solve_t(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int t0, int T) const
+        __device__ __forceinline__ void panel_solve_t(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int t0, int T) const
         {
             int const lane = t0 & 63, wv = __builtin_amdgcn_readfirstlane(t0 >> 6), nwv = T >> 6;
             int const nrows = m - k0 - KB, ncolL = p - k0 - KB, ncols = ncolL + u + (fuse ? 1 : 0);
-            Blk8 const B8 = blk_load(Lp + k0 + k0 * m, m, KB, lane);
+            Blk8 const B8 = blk_load(Lp + k0 + k0 * ld, ld, KB, lane);
             int const row_items = (nrows + 63) >> 6, col_items = (ncols + 63) >> 6;
             double const* rd = rdiag();
             for(int item = wv; item < row_items + col_items; item += nwv)
@@ -135,9 +135,9 @@ namespace pe
                 {
                     int const i = item * 64 + lane;
                     bool const own = i < nrows;
-                    double* row = Lp + (k0 + KB + (own ? i : nrows - 1)) + k0 * m;
+                    double* row = Lp + (k0 + KB + (own ? i : nrows - 1)) + k0 * ld;
 #pragma unroll
-                    for(int kk = 0; kk < KB; ++kk) x[kk] = row[kk * m];
+                    for(int kk = 0; kk < KB; ++kk) x[kk] = row[kk * ld];
 #pragma unroll
                     for(int kk = 0; kk < KB; ++kk)
                     {
@@ -149,7 +149,7 @@ namespace pe
                     if(own)
                     {
 #pragma unroll
-                        for(int kk = 0; kk < KB; ++kk) row[kk * m] = x[kk];
+                        for(int kk = 0; kk < KB; ++kk) row[kk * ld] = x[kk];
                     }
                 }
                 else
@@ -157,7 +157,7 @@ namespace pe
                     int const jj = (item - row_items) * 64 + lane;
                     bool const own = jj < ncols;
                     int const j = own ? jj : ncols - 1;
-                    double* col = j < ncolL ? Lp + (k0 + KB + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                    double* col = j < ncolL ? Lp + (k0 + KB + j) * ld + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
 #pragma unroll
                     for(int kk = 0; kk < KB; ++kk) x[kk] = col[kk];
 #pragma unroll
@@ -176,18 +176,18 @@ namespace pe
                 }
             }
         }
-        __device__ __forceinline__ void panel_solve(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int t0, int T) const
+        __device__ __forceinline__ void panel_solve(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int t0, int T) const
         {
             switch(kb)
             {
-                case 8: return panel_solve_t<8>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 7: return panel_solve_t<7>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 6: return panel_solve_t<6>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 5: return panel_solve_t<5>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 4: return panel_solve_t<4>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 3: return panel_solve_t<3>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                case 2: return panel_solve_t<2>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
-                default: return panel_solve_t<1>(Lp, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 8: return panel_solve_t<8>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 7: return panel_solve_t<7>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 6: return panel_solve_t<6>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 5: return panel_solve_t<5>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 4: return panel_solve_t<4>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 3: return panel_solve_t<3>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                case 2: return panel_solve_t<2>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
+                default: return panel_solve_t<1>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, t0, T);
             }
         }
 
@@ -220,14 +220,14 @@ namespace pe
         // straight-line code with no branch per entry; lanes outside the front work on a clamped row / column (valid
         // addresses, results dropped) and rows not below the pivot take a zero multiplier instead of an exec mask.
         template <int KB>
-        __device__ __forceinline__ int block_step_t(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int lane) const
+        __device__ __forceinline__ int block_step_t(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, bool fuse, int lane) const
         {
             int const nrow = m - k0;  // >= KB >= 1
             bool const own = lane < nrow;
-            double* row = Lp + (k0 + (own ? lane : nrow - 1)) + k0 * m;
+            double* row = Lp + (k0 + (own ? lane : nrow - 1)) + k0 * ld;
             double v[KB];
 #pragma unroll
-            for(int c = 0; c < KB; ++c) v[c] = row[c * m];
+            for(int c = 0; c < KB; ++c) v[c] = row[c * ld];
             int bad = 0;
 #pragma unroll
             for(int kk = 0; kk < KB; ++kk)
@@ -244,14 +244,14 @@ namespace pe
             if(own)
             {
 #pragma unroll
-                for(int c = 0; c < KB; ++c) row[c * m] = v[c];
+                for(int c = 0; c < KB; ++c) row[c * ld] = v[c];
             }
             int const ncolL = p - k0 - KB, ncols = ncolL + u + (fuse ? 1 : 0);
             if(ncols > 0)
             {
                 bool const ownc = lane < ncols;
                 int const j = ownc ? lane : ncols - 1;
-                double* col = j < ncolL ? Lp + (k0 + KB + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                double* col = j < ncolL ? Lp + (k0 + KB + j) * ld + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
                 double x[KB];
 #pragma unroll
                 for(int kk = 0; kk < KB; ++kk) x[kk] = col[kk];
@@ -271,19 +271,19 @@ namespace pe
             }
             return bad;
         }
-        __device__ __forceinline__ int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse,
+        __device__ __forceinline__ int block_step(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse,
                                                   int lane) const
         {
             switch(kb)
             {
-                case 8: return block_step_t<8>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 7: return block_step_t<7>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 6: return block_step_t<6>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 5: return block_step_t<5>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 4: return block_step_t<4>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 3: return block_step_t<3>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                case 2: return block_step_t<2>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
-                default: return block_step_t<1>(Lp, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 8: return block_step_t<8>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 7: return block_step_t<7>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 6: return block_step_t<6>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 5: return block_step_t<5>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 4: return block_step_t<4>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 3: return block_step_t<3>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                case 2: return block_step_t<2>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
+                default: return block_step_t<1>(Lp, ld, m, Up, ldu, g, p, u, k0, fuse, lane);
             }
         }
         // Triangular solves of the triangular-solve phase, p <= 64, one wavefront: lane i owns t[i]; the dependent chain

@@ -595,7 +595,7 @@ namespace pe
                     for(int pp = std::min(rest, opt.max_pivots); pp >= 1; --pp)
                     {
                         long long const uch = (rest - pp) + ug, mch = pp + uch;
-                        if(static_cast<long long>(pp) * (mch + uch) <= opt.panel_doubles)
+                        if(static_cast<long long>(pe_ld(static_cast<int>(mch))) * pp + static_cast<long long>(pe_ld(pp)) * uch <= opt.panel_doubles)
                         {
                             pbest = pp;
                             break;
@@ -997,7 +997,7 @@ namespace pe
         for(int s = 0; s < nf; ++s)
         {
             int const m = S.f_p[s] + S.f_u[s];
-            if(S.f_kind[s] == 0) S.wave_panel_doubles = std::max<long long>(S.wave_panel_doubles, static_cast<long long>(S.f_p[s]) * (m + S.f_u[s]));
+            if(S.f_kind[s] == 0) S.wave_panel_doubles = std::max<long long>(S.wave_panel_doubles, static_cast<long long>(pe_ld(m)) * S.f_p[s] + static_cast<long long>(pe_ld(S.f_p[s])) * S.f_u[s]);
             for(int a = S.f_child_ptr[s]; a < S.f_child_ptr[s + 1]; ++a)
             {
                 int const c = S.f_child[a];
@@ -1040,12 +1040,13 @@ namespace pe
             long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
             long long const cap = S.f_kind[s] == 0 ? cap_wave : cap_team;
             int const ch0 = S.f_child_ptr[s], ch1 = S.f_child_ptr[s + 1];
-            bool const full = m * (m + 1) <= cap;
+            long long const ldl = pe_ld(static_cast<int>(m)), ldp = pe_ld(static_cast<int>(p));  // odd LDS leading dimensions (pe_device.hpp)
+            bool const full = ldl * m + m <= cap;
             bool const chain = !full && ch1 - ch0 == 1 && S.f_u[S.f_child[ch0]] == m;
             S.f_mode[s] = full ? 0 : (chain ? 2 : 1);
             if(!chain && ch1 > ch0)
             {
-                long long const nlds = full ? m * m : m * p + p * u;
+                long long const nlds = full ? ldl * m : ldl * p + ldp * u;
                 if(nlds + m > 65535)
                 {
                     S.error = "front image exceeds the 16-bit cell index of the assembly lists";
@@ -1073,16 +1074,16 @@ namespace pe
                     if(full)
                     {
                         for(long long j = 0; j < uc; ++j)
-                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * m, sp + i + j * uc);
+                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * ldl, sp + i + j * uc);
                     }
                     else
                     {
                         long long np = 0;  // the child's leading update rows that are pivots of this front (f_rel ascends)
                         while(np < uc && rel[np] < p) ++np;
                         for(long long j = 0; j < np; ++j)
-                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * m, sp + i + j * uc);            // L panel (columns < p)
+                            for(long long i = 0; i < uc; ++i) add(rel[i] + rel[j] * ldl, sp + i + j * uc);          // L panel (columns < p)
                         for(long long j = np; j < uc; ++j)
-                            for(long long i = 0; i < np; ++i) add(m * p + rel[i] + (rel[j] - p) * p, sp + i + j * uc);  // U panel (rows < p)
+                            for(long long i = 0; i < np; ++i) add(ldl * p + rel[i] + (rel[j] - p) * ldp, sp + i + j * uc);  // U panel (rows < p)
                     }
                     for(long long i = 0; i < uc; ++i) add(nlds + rel[i], sp + uc * uc + i);  // update vector -> right-hand-side column
                 }

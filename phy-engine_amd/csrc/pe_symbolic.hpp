@@ -14,6 +14,11 @@
 
 namespace pe
 {
+    // Leading dimension of a column-major front image / panel in LDS: odd, so that the lanes of an access that walks ACROSS
+    // columns (the column solves of a block step, the B operand of the MFMA tiles: stride = leading dimension) spread over the
+    // banks instead of piling onto gcd(2 ld, 64) of them -- ld = 32 puts all 64 lanes of such an access on one bank pair.
+    constexpr int pe_ld(int n) { return n | 1; }
+
     struct SymbolicOptions
     {
         int nd_leaf{24};          // stop dissecting below this many vertices (large circuits: 10, pe_engine.cpp symbolic_options, profiles/sweep_r02_leaf.log)

@@ -50,49 +50,49 @@ namespace pe
         };
         Blk8 blk_load(double const* blk, int ld, int, int) const { return Blk8{blk, ld}; }
         double blk_at(Blk8 const& b, int r, int c) const { return b.p[r + c * b.ld]; }
-        int block_step(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int) const
+        int block_step(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int) const
         {
             for(int kk = 0; kk < kb; ++kk)
             {
-                double const piv = Lp[(k0 + kk) + (k0 + kk) * m];
+                double const piv = Lp[(k0 + kk) + (k0 + kk) * ld];
                 if(piv == 0.0 || !(std::fabs(piv) <= 1.7976931348623157e308)) return 1;
                 double const r = emu_rcp(piv);
                 for(int i = k0 + kk + 1; i < m; ++i)
                 {
-                    double const l = Lp[i + (k0 + kk) * m] * r;
-                    for(int c = kk + 1; c < kb; ++c) Lp[i + (k0 + c) * m] -= l * Lp[(k0 + kk) + (k0 + c) * m];
-                    Lp[i + (k0 + kk) * m] = l;
+                    double const l = Lp[i + (k0 + kk) * ld] * r;
+                    for(int c = kk + 1; c < kb; ++c) Lp[i + (k0 + c) * ld] -= l * Lp[(k0 + kk) + (k0 + c) * ld];
+                    Lp[i + (k0 + kk) * ld] = l;
                 }
             }
             int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
             for(int j = 0; j < ncols; ++j)
             {
-                double* col = j < ncolL ? Lp + (k0 + kb + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                double* col = j < ncolL ? Lp + (k0 + kb + j) * ld + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
                 for(int kk = 1; kk < kb; ++kk)
-                    for(int r = 0; r < kk; ++r) col[kk] -= Lp[(k0 + kk) + (k0 + r) * m] * col[r];
+                    for(int r = 0; r < kk; ++r) col[kk] -= Lp[(k0 + kk) + (k0 + r) * ld] * col[r];
             }
             return 0;
         }
         // rows below / columns right of a factored kb x kb diagonal block (serial stand-in of the per-thread solves)
-        void panel_solve(double* Lp, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int, int) const
+        void panel_solve(double* Lp, int ld, int m, double* Up, int ldu, double* g, int p, int u, int k0, int kb, bool fuse, int, int) const
         {
-            double const* blk = Lp + k0 + k0 * m;
+            double const* blk = Lp + k0 + k0 * ld;
             for(int i = k0 + kb; i < m; ++i)
             {
-                double* row = Lp + i + k0 * m;
+                double* row = Lp + i + k0 * ld;
                 for(int kk = 0; kk < kb; ++kk)
                 {
-                    double acc = row[kk * m];
-                    for(int r = 0; r < kk; ++r) acc -= row[r * m] * blk[r + kk * m];
-                    row[kk * m] = acc * emu_rcp(blk[kk + kk * m]);
+                    double acc = row[kk * ld];
+                    for(int r = 0; r < kk; ++r) acc -= row[r * ld] * blk[r + kk * ld];
+                    row[kk * ld] = acc * emu_rcp(blk[kk + kk * ld]);
                 }
             }
             int const ncolL = p - k0 - kb, ncols = ncolL + u + (fuse ? 1 : 0);
             for(int j = 0; j < ncols; ++j)
             {
-                double* col = j < ncolL ? Lp + (k0 + kb + j) * m + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
+                double* col = j < ncolL ? Lp + (k0 + kb + j) * ld + k0 : (j < ncolL + u ? Up + (j - ncolL) * ldu + k0 : g + k0);
                 for(int kk = 1; kk < kb; ++kk)
-                    for(int r = 0; r < kk; ++r) col[kk] -= blk[kk + r * m] * col[r];
+                    for(int r = 0; r < kk; ++r) col[kk] -= blk[kk + r * ld] * col[r];
             }
         }
         int diag_lu8(double* blk, int ld, int kb, int) const
