@@ -770,6 +770,13 @@ namespace pe
             cost[s] = 400.0 + m * m * (2.0 + S.f_p[s]);
             total += cost[s];
             fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
+            if(fits[s] && opt.wave_slot > 0)
+            {
+                // (the slot also holds the right-hand-side column: m doubles behind the image / the panels)
+                long long const mm = S.f_p[s] + S.f_u[s], whole = (pe_ld(static_cast<int>(mm)) + 1LL) * mm,
+                                panel = static_cast<long long>(pe_ld(static_cast<int>(mm))) * S.f_p[s] + static_cast<long long>(pe_ld(S.f_p[s])) * S.f_u[s] + mm;
+                if(whole > opt.wave_slot && panel > opt.wave_slot) fits[s] = 0;
+            }
             sub[s] += cost[s];
             int const P = S.f_parent[s];
             if(P >= 0)
