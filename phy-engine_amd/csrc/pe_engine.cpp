@@ -320,7 +320,7 @@ namespace
         pe::SymbolicOptions so{};
         // Workgroup geometry by batch size (measured on MI355X, profiles/ and scripts/sweep_split_*.sh).
         // Large circuits run the split schedule (one launch per phase): from ~100 instances on, 256-thread workgroups at four per
-        // CU with every instance cut into 4 (8) parts -- >= 1024 workgroups for the low-register kernels; fewer instances keep one
+        // CU with every instance cut into 4 (8, 16) parts -- >= 1024 workgroups for the low-register kernels; fewer instances keep one
         // big workgroup per CU and more parts.  Small circuits run the resident kernel: geometry by the batch alone.
         bool const large = rows >= 3000 && env_int0("PHY_ENGINE_HIP_SPLIT", -1) != 0;
         bool const four_per_cu = large ? batch >= 96 : batch >= 768;
@@ -349,7 +349,9 @@ namespace
         }
         if(large)
         {
-            so.n_parts = batch >= 192 ? 4 : (batch >= 96 ? 8 : std::clamp(256 / std::max(1, batch), 1, 48));
+            // (re-swept after the larger wave-front class: 128 instances 16 parts 1.65 ms per iteration against 1.68 with 8 and 1.77 with 12;
+            //  256 instances 8 parts 2.74 against 2.81 with 4; 512 and 1 024 instances stay at 4)
+            so.n_parts = batch >= 384 ? 4 : (batch >= 192 ? 8 : (batch >= 96 ? 16 : std::clamp(256 / std::max(1, batch), 1, 48)));
             so.part_cut = 1.0;
             so.nd_leaf = 10;  // finer dissection: fewer, better-shaped fronts on big meshes (-3.6 % per iteration on M10k, profiles/sweep_r02_leaf.log);
                               // small circuits keep 24 (their whole graph is one minimum-degree leaf, as validated by every golden)
