@@ -212,6 +212,31 @@ assert list(trace) == meta['newton_iters']
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
 
 
+@pytest.mark.parametrize("name,geometry", [("mesh32_nl_seed2", "1024"), ("mesh32_lin", "1024"), ("ladder_c1", "1024"), ("bridge_c2", "1024")])
+def test_sweep_geometry_under_host_emulation(emu_lib, name, geometry):
+    """The launch geometry of the 1 024-instance sweep (four 4-wavefront workgroups per CU, split schedule) on the host emulation:
+    wave fronts up to order 45 -- whole in the 10 KB slot up to 35, in the panel layout above (SymbolicOptions::wave_slot) -- the
+    odd LDS leading dimensions and the lean backward pass (front_backward_lean), against the reference goldens."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+os.environ['PHY_ENGINE_HIP_GEOMETRY_BATCH'] = {geometry!r}
+os.environ['PHY_ENGINE_HIP_SPLIT'] = '1'
+os.environ['PHY_ENGINE_HIP_PARTS'] = '4'
+sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np
+from parity_common import *
+meta, gx, deck = golden({name!r})
+eng = pe.ffi.Engine()
+snaps, trace, fail = run_engine_case(eng, meta, deck)
+assert fail == -1 and len(snaps) == len(gx)
+assert max_err(snaps[:, 0, :], gx, 1e-9, 1e-6) <= 1.0
+assert list(trace) == meta['newton_iters']
+assert eng.info()['n_wavefronts'] == 4 and eng.info()['n_parts'] == 4
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=300)
+
+
 @pytest.mark.parametrize("name", ["ac_rc_lowpass", "ac_rlc_diode_acop", "ac_linear_mix", "ac_nmos_amp"])
 def test_ac_real_equivalent_system_under_host_emulation(emu_lib, name):
     """The AC path's host logic (real-equivalent 2N system, value vector per omega, operating-point hand-over) with the
