@@ -464,6 +464,9 @@ namespace
                 std::fprintf(stderr, "[pe_hip]   %s fronts (cap ~%lld doubles): whole %lld (S %lld, panels %lld) | panel+pull %lld (S %lld, panels %lld) | chain link %lld (S %lld, panels %lld)\n",
                              kind == 0 ? "wave" : "cooperative", cap, cnt[0], su2[0], spanel[0], cnt[1], su2[1], spanel[1], cnt[2], su2[2], spanel[2]);
             }
+            if(dump[1] == '3')
+                for(int s = 0; s < S.nfronts; ++s)
+                    if(S.f_kind[s] == 0) std::fprintf(stderr, "[pe_hip]   wave front %d: %dx%d children %d\n", s, S.f_p[s] + S.f_u[s], S.f_p[s], S.f_child_ptr[s + 1] - S.f_child_ptr[s]);
             if(dump[1] == '2')
                 for(int s = 0; s < S.nfronts; ++s)
                     if(S.f_kind[s] == 1) std::fprintf(stderr, "[pe_hip]   coop front %d: %dx%d children %d\n", s, S.f_p[s] + S.f_u[s], S.f_p[s], S.f_child_ptr[s + 1] - S.f_child_ptr[s]);
