@@ -815,4 +815,20 @@ namespace pe
             avals[s] = acc;
         }
     }
+    std::vector<char> dynamic_dv_mask(HostCircuit const& hc)
+    {
+        std::vector<char> m(static_cast<size_t>(std::max(hc.dv_len, 1)), 0);
+        auto mark = [&](int o, int n)
+        {
+            for(int k = 0; k < n; ++k)
+                if(o + k >= 0 && o + k < hc.dv_len) m[static_cast<size_t>(o + k)] = 1;
+        };
+        mark(hc.dv_dg, hc.nD());
+        mark(hc.dv_di, hc.nD());
+        mark(hc.dv_ova, hc.n_ov_a);
+        mark(hc.dv_ovb, hc.n_ov_b);
+        for(auto const& d: hc.gen)
+            if(d.kind == PE_HIP_RELAY || (d.kind >= PE_HIP_NMOS && d.kind <= PE_HIP_BJT_PNP)) mark(d.dv, gen_ndv(d.kind));
+        return m;
+    }
 }  // namespace pe

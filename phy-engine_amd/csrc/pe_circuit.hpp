@@ -112,4 +112,7 @@ namespace pe
     // Representative |values| of the A slots of instance 0 for the row matching (TR: capacitors 2C/dt, inductors
     // 2L/dt; DC-like: open / short), diodes at their zero-bias conductance.
     void estimate_values(HostCircuit const& hc, bool tr_mode, double dt, double gmin, double r_open, std::vector<double>& avals);
+    // dv entries written from the current iterate x (junction, MOS / BJT, relay values; host-stamp overlay): what changes between the
+    // Newton iterations of one solve point
+    std::vector<char> dynamic_dv_mask(HostCircuit const& hc);
 }  // namespace pe

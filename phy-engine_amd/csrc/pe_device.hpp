@@ -60,6 +60,10 @@ namespace pe
         // ---- stamping: CSR of contributions per A slot / per RHS row; entry = (dv index << 1) | negate
         int const *a_ptr, *a_src;
         int const *b_ptr, *b_src;
+        // slots of aval / rows of rhs with a contribution that depends on x (junctions, MOS / BJT, relays, host-stamp overlay): the
+        // only ones that change between the Newton iterations of one solve point (null: not built -- always stamp everything)
+        int const *dyn_a{}, *dyn_b{};
+        int n_dyn_a{}, n_dyn_b{};
         // ---- per-instance parameters  [batch][count(*cols)]
         double const* c_cap;
         double const* l_ind;

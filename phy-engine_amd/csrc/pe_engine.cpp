@@ -501,6 +501,34 @@ namespace
             if(src2.empty()) src2.push_back(0);
             HIPCHK(h, h->sym_pool.upload(h->V.a_ptr, ptr2));
             HIPCHK(h, h->sym_pool.upload(h->V.a_src, src2));
+            // x-dependent slots / rows (pe_front.hpp stamp_dynamic_chunk): Newton iterations after the first stamp only these
+            h->V.dyn_a = h->V.dyn_b = nullptr;
+            h->V.n_dyn_a = h->V.n_dyn_b = 0;
+            if(hc.nonlinear)
+            {
+                std::vector<char> const dyn = pe::dynamic_dv_mask(hc);
+                std::vector<int> da, db;
+                for(size_t e = 0; e < nnz; ++e)
+                    for(int k = ptr2[e]; k < ptr2[e + 1]; ++k)
+                        if(dyn[static_cast<size_t>(src2[k] >> 1)])
+                        {
+                            da.push_back(static_cast<int>(e));
+                            break;
+                        }
+                for(int r = 0; r < hc.rows; ++r)
+                    for(int k = hc.b_ptr[r]; k < hc.b_ptr[r + 1]; ++k)
+                        if(dyn[static_cast<size_t>(hc.b_src[k] >> 1)])
+                        {
+                            db.push_back(r);
+                            break;
+                        }
+                h->V.n_dyn_a = static_cast<int>(da.size());
+                h->V.n_dyn_b = static_cast<int>(db.size());
+                if(da.empty()) da.push_back(0);
+                if(db.empty()) db.push_back(0);
+                HIPCHK(h, h->sym_pool.upload(h->V.dyn_a, da));
+                HIPCHK(h, h->sym_pool.upload(h->V.dyn_b, db));
+            }
             h->V.asm_slot = nullptr;  // identity (pe_front.hpp front_factor); the solve_csr_real seam keeps CSR order + the map
             std::vector<int> slot_e(nnz, 0);  // CSR slot -> position in aval (residual check walks A row by row in original order)
             for(size_t e = 0; e < nnz; ++e) slot_e[S.asm_slot[e]] = static_cast<int>(e);
@@ -722,7 +750,7 @@ namespace
             if(has_overlay(h))
                 if(int const rc = overlay_call(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step); rc != PE_HIP_OK) return rc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1));
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0));
             ++launches;
             if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK) return drc;  // (synchronises the stream)
             {

@@ -398,17 +398,21 @@ namespace pe
     // out[s] = sum over the contribution list of slot s, in list order; four slots per thread in flight (the three
     // dependent loads ptr -> src -> dv of one slot would otherwise be fully exposed)
     // (t0, T): this thread's index and the thread count of the group that shares the slot range [lo, hi)
-    PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n)
+    // `list` != null: the slots are list[lo .. n) instead of lo .. n
+    PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n, int const* list = nullptr)
     {
         for(int base = lo + t0; base < n; base += 4 * T)
         {
+            int slot[4];
             int e[4], end[4];
             double acc[4];
 #pragma unroll
             for(int q = 0; q < 4; ++q)
             {
-                int const s = base + q * T;
-                bool const ok = s < n;
+                int const k = base + q * T;
+                bool const ok = k < n;
+                int const s = ok ? (list ? list[k] : k) : 0;
+                slot[q] = s;
                 e[q] = ok ? ptr[s] : 0;
                 end[q] = ok ? ptr[s + 1] : 0;
                 acc[q] = 0.0;
@@ -434,7 +438,7 @@ namespace pe
             }
 #pragma unroll
             for(int q = 0; q < 4; ++q)
-                if(base + q * T < n) out[base + q * T] = acc[q];
+                if(base + q * T < n) out[slot[q]] = acc[q];
         }
     }
 
@@ -448,6 +452,23 @@ namespace pe
     // the same with the slots dealt out in CONTIGUOUS chunks to G groups of T threads (split schedule: one workgroup per chunk).
     // The matrix slots are in front-assembly order, so a chunk is a patch of the circuit and the device values it gathers are
     // few enough to stay in the CU's L1: a 64-byte sector of dv is fetched from L2 once per chunk instead of once per lane.
+    // Newton iterations after the first of a solve point: only the slots an x-dependent device contributes to are gathered again
+    // (same lists, same summation order: bit-identical to a full stamp); everything else still holds the first iteration's values.
+    PE_DEV void stamp_dynamic_chunk(DevView const& V, int b, int g, int G, int t0, int T)
+    {
+        double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
+        auto range = [&](int n, int& lo, int& hi)
+        {
+            int const c = (n + G - 1) / G;
+            lo = g * c < n ? g * c : n;
+            hi = lo + c < n ? lo + c : n;
+        };
+        int lo, hi;
+        range(V.n_dyn_a, lo, hi);
+        gather_contributions(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi, V.dyn_a);
+        range(V.n_dyn_b, lo, hi);
+        gather_contributions(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b);
+    }
     PE_DEV void stamp_chunk(DevView const& V, int b, int g, int G, int t0, int T)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;

@@ -637,10 +637,12 @@ namespace pe
         }
     }
 
-    __global__ void __launch_bounds__(256) k_m2_stamp(DevView V)
+    __global__ void __launch_bounds__(256) k_m2_stamp(DevView V, int dynamic_only)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
+        if(dynamic_only) stamp_dynamic_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+        else
         stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     }
 
@@ -919,7 +921,8 @@ namespace pe
     // ev0 / ev1 (may be null): HIP events recorded around the dominant launch (k_m2_factor_parts, or the backward
     // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
     template <int MINW>
-    static hipError_t m2_sequence(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1, bool refine)
+    static hipError_t m2_sequence(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1, bool refine,
+                                  bool stamp_dynamic = false)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
@@ -952,7 +955,7 @@ namespace pe
         if(!refine)
         {
             hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
-            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V);
+            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);
         }
         // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)
         hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
@@ -1008,10 +1011,11 @@ namespace pe
         return hipGetLastError();
     }
 
-    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1)
+    hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1,
+                                   bool stamp_dynamic)
     {
-        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false)
-                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false);
+        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic)
+                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic);
     }
 
     // One round of iterative refinement of the active instances' last solve (same matrix values, same pivot order):

@@ -195,7 +195,7 @@ namespace pe
             if(V.active[b]) companion_update(SerialTeam{1}, V, b, dt);
         return hipSuccess;
     }
-    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t)
+    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, bool stamp_dynamic)
     {
         std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
         SerialTeam tm{V.n_waves};
@@ -211,7 +211,9 @@ namespace pe
             V.flags[b] = 0;
             if(V.eta_acc)
                 for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
-            stamp(tm, V, b);
+            if(stamp_dynamic && V.dyn_a && V.dyn_b) stamp_dynamic_chunk(V, b, 0, 1, 0, 1);
+            else
+                stamp(tm, V, b);
             for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
             if(do_factor)
             {

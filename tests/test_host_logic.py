@@ -182,7 +182,11 @@ def emu_lib():
 
 @pytest.mark.parametrize("name,parts", [("rc_step", 1), ("rlc_series_vl_trop", 1), ("diode_op", 1), ("bridge_c2", 1), ("mesh32_nl_seed2", 1),
                                         ("ladder_c1", 1), ("mesh32_nl_seed2", 6), ("mesh32_lin", 16), ("ladder_c1", 4),
-                                        ("mesh32_nl_seed2", -1), ("mesh32_lin", -4), ("ladder_c1", -1)] +
+                                        ("mesh32_nl_seed2", -1), ("mesh32_lin", -4), ("ladder_c1", -1),
+                                        # split schedule with every kind of x-dependent device: Newton iterations after the first stamp
+                                        # only the slots those devices contribute to (stamp_dynamic_chunk)
+                                        ("cmos_inverter_tr", 4), ("bjt_amp_tr", 4), ("relay_ramp_tr", 4), ("nmos_triode_op", 4), ("bridge_c2", 4),
+                                        ("diode_op", 2)] +
                          [(n, 1) for n in ("vccs_dc", "vcvs_gain", "cccs_dc", "ccvs_dc", "op_amp_follower", "transformer_ratio", "generator_dc",
                                            "switch_open_dc", "switch_closed_dc", "switch_open_ropen1e6_dc", "generators_tr", "generators_trop",
                                            "iac_rc_tr", "iac_rc_dc", "iac_rc_trop", "coupled_l_k0_tr", "coupled_l_k09_tr", "coupled_l_k09_trop",
