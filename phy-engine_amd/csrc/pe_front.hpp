@@ -193,11 +193,15 @@ namespace pe
     // device evaluation: fills the dynamic part of dv for this Newton iteration
     // ------------------------------------------------------------------------------------------------
     template <class Team>
-    PE_DEV void eval_devices(Team const& tm, DevView const& V, int b, int mode, double t, double last_step)
+    // dynamic_only: a later Newton iteration of the same solve point -- the values that do not depend on x (companions, sources at
+    // this t) are still in dv from the first one
+    PE_DEV void eval_devices(Team const& tm, DevView const& V, int b, int mode, double t, double last_step, bool dynamic_only = false)
     {
         double const* x = V.x + static_cast<long long>(b) * V.rows;
         double* dv = V.dv + static_cast<long long>(b) * V.dv_len;
         bool const tr = mode == MODE_TR;
+        if(!dynamic_only)
+        {
         {
             double const* hist = V.c_hist + static_cast<long long>(b) * V.nC;
             double const* prevg = V.c_prevg + static_cast<long long>(b) * V.nC;
@@ -272,6 +276,7 @@ namespace pe
                     e = par[3 * i] * sin(par[3 * i + 1] * 0.0 + par[3 * i + 2]);
                 dv[V.dv_vac + i] = e;
             }
+        }
         }
         {
             // relays: the contact follows the coil voltage of the current iterate with hysteresis (relay.h:84-95)

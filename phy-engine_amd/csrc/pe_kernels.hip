@@ -620,7 +620,7 @@ namespace pe
         companion_update(GridTeam{}, V, b, dt);
     }
 
-    __global__ void __launch_bounds__(256) k_m2_eval(DevView V, int mode, double t, double last_step)
+    __global__ void __launch_bounds__(256) k_m2_eval(DevView V, int mode, double t, double last_step, int dynamic_only)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -628,7 +628,7 @@ namespace pe
         double const* x = V.x + static_cast<long long>(b) * V.rows;
         double* xp = V.xprev + static_cast<long long>(b) * V.rows;
         for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
-        eval_devices(tm, V, b, mode, t, last_step);
+        eval_devices(tm, V, b, mode, t, last_step, dynamic_only != 0);
         if(tm.tid() == 0)
         {
             V.flags[b] = 0;
@@ -954,7 +954,7 @@ namespace pe
         };
         if(!refine)
         {
-            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step);
+            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);
             hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);
         }
         // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)

@@ -207,7 +207,7 @@ namespace pe
             double* w = V.w + static_cast<long long>(b) * V.rows;
             double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
             for(int r = 0; r < V.rows; ++r) xp[r] = x[r];
-            eval_devices(tm, V, b, mode, t, last_step);
+            eval_devices(tm, V, b, mode, t, last_step, stamp_dynamic && V.dyn_a && V.dyn_b);
             V.flags[b] = 0;
             if(V.eta_acc)
                 for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
