@@ -750,7 +750,9 @@ namespace
             if(has_overlay(h))
                 if(int const rc = overlay_call(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step); rc != PE_HIP_OK) return rc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0));
+            // (test knob PHY_ENGINE_HIP_FULL_STAMP=1: every iteration stamps everything -- the x-dependent-only path must match it bit for bit)
+            static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0 && !full_stamp));
             ++launches;
             if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK) return drc;  // (synchronises the stream)
             {

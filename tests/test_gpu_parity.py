@@ -770,3 +770,35 @@ def test_residual_safety_net_paths_on_gpu():
             assert max_err(x[k], o.x, *LIN) <= 1.0
     finally:
         e.close()
+
+
+def test_x_dependent_only_stamp_is_bit_identical(tmp_path):
+    """Newton iterations after the first of a time point stamp only the slots an x-dependent device contributes to (same lists, same
+    order: pe_front.hpp stamp_dynamic_chunk) and evaluate only those devices.  Against PHY_ENGINE_HIP_FULL_STAMP=1 (everything,
+    every iteration) the solutions of a 4-instance M10k-NL sweep must agree bit for bit, with the same Newton counts.  The knob is
+    read once per process: two subprocesses (one GPU process at a time)."""
+    import subprocess
+    import sys
+    from parity_common import ROOT
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load()
+deck, r, c = pe.deck.rc_mesh_params(100, 100, [3, 4, 5, 6], True)
+e = pe.ffi.Engine(device=0); e.set_options(g_min=0.0)
+e.load_deck(deck, batch=4, overrides={{"R": r[:, :, None], "C": c[:, :, None]}})
+e.reset(); st = e.analyze_tr(1e-10, 12)
+assert e.info()["n_parts"] > 1 and e.info()["nonlinear"] == 1
+np.save(sys.argv[1], e.solution()); np.save(sys.argv[1] + ".it", e.state()["iters"])
+e.close()
+"""
+    out = []
+    for knob in ("0", "1"):
+        f = str(tmp_path / f"x{knob}.npy")
+        env = dict(os.environ, PHY_ENGINE_HIP_FULL_STAMP=knob, PHY_ENGINE_HIP_GEOMETRY_BATCH="1024")
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=600)
+        out.append((np.load(f), np.load(f + ".it.npy")))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][0], out[1][0])   # bit for bit
+    assert out[0][1].min() > 12                   # (several Newton iterations per step: the x-dependent-only path did run)

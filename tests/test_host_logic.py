@@ -413,3 +413,30 @@ else:
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
     subprocess.run(["python3", "-c", code], check=True, timeout=300, env=dict(os.environ, PE_EMU_PIVOT_ERROR="1e-7"))
+
+
+def test_x_dependent_only_stamp_is_bit_identical_under_host_emulation(emu_lib, tmp_path):
+    """The same as tests/test_gpu_parity.py::test_x_dependent_only_stamp_is_bit_identical, on the host emulation with every kind of
+    x-dependent device in the split schedule (junctions, MOS, BJT, relay)."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+os.environ['PHY_ENGINE_HIP_PARTS'] = '4'
+sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np
+from parity_common import *
+res = []
+for name in ("mesh32_nl_seed2", "cmos_inverter_tr", "bjt_amp_tr", "relay_ramp_tr", "bridge_c2"):
+    meta, gx, deck = golden(name)
+    eng = pe.ffi.Engine()
+    snaps, trace, fail = run_engine_case(eng, meta, deck)
+    assert eng.info()['n_parts'] == 4
+    res.append(np.asarray(snaps).ravel()); res.append(np.asarray(trace, dtype=float))
+np.save(sys.argv[1], np.concatenate(res))
+"""
+    out = []
+    for knob in ("0", "1"):
+        f = str(tmp_path / f"x{knob}.npy")
+        subprocess.run(["python3", "-c", code, f], check=True, timeout=600, env=dict(os.environ, PHY_ENGINE_HIP_FULL_STAMP=knob))
+        out.append(np.load(f))
+    assert np.array_equal(out[0], out[1])
