@@ -137,6 +137,13 @@ namespace pe
         int lds_solve_doubles;  // ... of the triangular-solve kernels of the split schedule
         // lean plan of the backward pass (front_backward_lean: only U11 staged): slot, stack offset, staged block, launch size
         int lds_sslot_b{}, lds_bstack_off_b{}, lds_wave_stage_b{}, lds_solve_b_doubles{};
+        // ---- lane-group kernel of the wave fronts (pe_quad.hpp; tables: pe_symbolic.hpp "quad plan")
+        int quad{};                    // 1: the wave fronts of the split schedule run on k_m2_factor_quads, factor_part skips them
+        int const *q_prog{}, *q_lists{};
+        unsigned char const* q_lane{};
+        long long q_zero_off{};        // zero region of every instance's arena (doubles)
+        int const* q_list{};           // [n_quads][4] instances of a quad (-1: none), ascending; all within one 32-bit byte-offset window of [0]
+        int n_quads{};
         // ---- Newton
         double v_abstol, v_reltol, i_abstol, i_reltol;
         int max_newton;

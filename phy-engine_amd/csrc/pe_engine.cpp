@@ -226,6 +226,8 @@ namespace
         return v && *v ? std::max(1, std::atoi(v)) : batch;
     }
 
+    int env_int0(char const* name, int def);
+
     int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
     {
         V.nfronts = S.nfronts;
@@ -302,6 +304,19 @@ namespace
         HIPCHK(h, pool.upload(V.gl_cnt, S.gl_cnt));
         HIPCHK(h, pool.upload(V.gl_src, S.gl_src));
         HIPCHK(h, pool.alloc(V.zero, 1));
+        // lane-group kernel of the wave fronts (pe_quad.hpp): its tables; V.q_list / V.n_quads follow the `active` mask (upload_active)
+        V.quad = 0;
+        if(S.quad)
+        {
+            HIPCHK(h, pool.upload(V.q_prog, S.q_prog));
+            HIPCHK(h, pool.upload(V.q_lists, S.q_lists));
+            HIPCHK(h, pool.upload(V.q_lane, S.q_lane));
+            V.q_zero_off = S.q_zero_off;
+            // a quad addresses its four instances by 32-bit byte offsets from the first one: every per-instance array must leave room
+            // for at least one instance inside 4 GiB (else the wave fronts fall back to the per-instance path of factor_part)
+            long long const stride = 8 * std::max({static_cast<long long>(S.nnzA), V.factor_doubles, V.arena_doubles, static_cast<long long>(S.n)});
+            V.quad = stride < (1ll << 31) ? (env_int0("PHY_ENGINE_HIP_QUAD", 1) | 1) : 0;
+        }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
         return PE_HIP_OK;
@@ -362,6 +377,16 @@ namespace
             char const* v = std::getenv(name);
             return v && *v ? std::atoi(v) : def;
         };
+        // the wave fronts of a large sweep run four instances per wavefront on the lane-group kernel (pe_quad.hpp): fronts of order
+        // <= 32 with <= 16 pivots; larger ones stay with the cooperative phase
+        so.quad = (four_per_cu && large && env_int("PHY_ENGINE_HIP_QUAD", 1) != 0) ? 1 : 0;
+        if(so.quad)
+        {
+            so.wave_m = 32;
+            so.wave_slot = 0;
+            so.wave_p = 16;
+            so.absorb_m = 32;
+        }
         so.n_waves = std::clamp(env_int("PHY_ENGINE_HIP_WAVES", so.n_waves), 1, PE_THREADS / 64);
         so.wave_m = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_M", so.wave_m));
         so.wave_p = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_P", so.wave_p));
@@ -480,6 +505,7 @@ namespace
         h->sym_pool.release();
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
+        h->active_dev.clear();  // (the quad list behind the mask depends on this analysis' strides)
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
             std::fprintf(stderr, "[pe_hip]   LDS plan (doubles): factor %d, solves %d, backward %d (wave slot %d = t %d + stage %d + 64 + stack %d), wave front slot %d\n", h->V.lds_doubles,
                          h->V.lds_solve_doubles, h->V.lds_solve_b_doubles, h->V.lds_sslot, h->V.wave_m, h->V.lds_wave_stage, h->V.lds_sslot - h->V.lds_bstack_off, h->V.lds_slot);
@@ -654,13 +680,41 @@ namespace
     }
     // `active` mask of the next launches (stream-ordered).  The caller synchronises the stream before it changes the mask again,
     // so the one pinned staging buffer is free by then.
+    // Quad mode: the active instances, ascending, are packed four to a wavefront of the lane-group kernel (pe_quad.hpp) -- behind the
+    // mask in the same buffer / the same copy.  A quad addresses its members by 32-bit byte offsets from its first one, so it only
+    // takes instances inside that window (a sparse tail of a sweep gives short quads, padded with -1).
     int upload_active(pe_hip_engine* h, std::vector<int> const& mask)
     {
         if(h->active_dev == mask) return PE_HIP_OK;
-        if(int const rc = ensure_pinned(h, mask.size()); rc != PE_HIP_OK) return rc;
+        size_t const B = mask.size();
+        if(int const rc = ensure_pinned(h, 5 * B); rc != PE_HIP_OK) return rc;
         HIPCHK(h, hipStreamSynchronize(h->stream));  // (an earlier upload from the staging buffer may still be in flight)
         std::copy(mask.begin(), mask.end(), h->pin_active);
-        HIPCHK(h, hipMemcpyAsync(h->V.active, h->pin_active, mask.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        size_t words = B;
+        if(h->V.quad)
+        {
+            long long const stride = 8 * std::max({static_cast<long long>(h->V.nnzA), h->V.factor_doubles, h->V.arena_doubles, static_cast<long long>(h->V.rows)});
+            long long const span = std::max<long long>(0, ((1ll << 32) - 1) / std::max<long long>(stride, 1) - 2);
+            int* ql = h->pin_active + B;
+            int nq = 0, cnt = 0, first = 0;
+            for(size_t b = 0; b < B; ++b)
+            {
+                if(!mask[b]) continue;
+                if(cnt == 0 || cnt == 4 || static_cast<long long>(b) - first > span)
+                {
+                    for(; cnt > 0 && cnt < 4; ++cnt) ql[4 * (nq - 1) + cnt] = -1;
+                    ++nq;
+                    cnt = 0;
+                    first = static_cast<int>(b);
+                }
+                ql[4 * (nq - 1) + cnt++] = static_cast<int>(b);
+            }
+            for(; cnt > 0 && cnt < 4; ++cnt) ql[4 * (nq - 1) + cnt] = -1;
+            h->V.n_quads = nq;
+            h->V.q_list = h->V.active + B;
+            words = B + 4 * static_cast<size_t>(nq);
+        }
+        HIPCHK(h, hipMemcpyAsync(h->V.active, h->pin_active, words * sizeof(int), hipMemcpyHostToDevice, h->stream));
         h->active_dev = mask;
         return PE_HIP_OK;
     }
@@ -1188,7 +1242,7 @@ int finish_load(pe_hip_engine* h)
         HIPCHK(h, P.alloc(h->stats_scratch, need, false));
         h->stats_doubles = need;
     }
-    HIPCHK(h, P.alloc(V.active, B));
+    HIPCHK(h, P.alloc(V.active, 5 * B));  // the mask + the quad list of the lane-group kernel behind it (upload_active)
     HIPCHK(h, P.alloc(V.flags, B));
     // residual safety net: CSR of A in original order (shared) + per-instance refinement buffers
     HIPCHK(h, P.upload(V.csr_rp, hc.rp));

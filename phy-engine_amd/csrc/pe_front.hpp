@@ -1028,6 +1028,7 @@ namespace pe
         int fail = 0;
         long long const c0 = tm.clock();
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
+        if(!V.quad)  // (quad mode: the wave fronts were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
         tm.for_each_wave(
             [&](int w, int lane, int NL)
             {
@@ -1365,6 +1366,7 @@ namespace pe
     PE_DEV void forward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
+        if(!V.quad)  // (quad mode: the wave fronts were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
             {

@@ -21,6 +21,7 @@
 
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
+#include "pe_quad.hpp"
 
 namespace pe
 {
@@ -867,6 +868,96 @@ namespace pe
         if(bits) atomicOr(V.flags + b, bits);
     }
 
+    // ---- lane-group kernel of the wave fronts (pe_quad.hpp): the device execution model.  One lane's view; the 64 lanes of the
+    // wavefront run in lockstep under wavefront-uniform control flow, so every cross-lane read is a DPP broadcast inside a row of 16.
+    extern "C" __device__ double pe_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
+    struct QuadDev
+    {
+        using vd = double;
+        using vi = int;
+        using vu = unsigned;
+        using vm = bool;
+        static __device__ __forceinline__ vi lane() { return static_cast<int>(threadIdx.x) & 63; }
+        static __device__ __forceinline__ vu to_u(vi v) { return static_cast<unsigned>(v); }
+        // DPP row_newbcast:K (dpp_ctrl 0x150 + K): lane K of each row of 16 lanes to the whole row -- v_mov_b64_dpp, one instruction
+        template <int K>
+        static __device__ __forceinline__ vd bc(vd v)
+        {
+            return pe_update_dpp_f64(v, v, 0x150 + K, 0xf, 0xf, true);
+        }
+        static __device__ __forceinline__ vd bcast(vd v, int k)  // k is a constant after unrolling: the switch folds
+        {
+            switch(k)
+            {
+                case 0: return bc<0>(v);
+                case 1: return bc<1>(v);
+                case 2: return bc<2>(v);
+                case 3: return bc<3>(v);
+                case 4: return bc<4>(v);
+                case 5: return bc<5>(v);
+                case 6: return bc<6>(v);
+                case 7: return bc<7>(v);
+                case 8: return bc<8>(v);
+                case 9: return bc<9>(v);
+                case 10: return bc<10>(v);
+                case 11: return bc<11>(v);
+                case 12: return bc<12>(v);
+                case 13: return bc<13>(v);
+                case 14: return bc<14>(v);
+                default: return bc<15>(v);
+            }
+        }
+        static __device__ __forceinline__ vd ld(char const* base, vu off) { return *reinterpret_cast<double const*>(base + off); }
+        static __device__ __forceinline__ void ld_u32x4(unsigned char const* base, vu off, vu* out)
+        {
+            uint4 const t = *reinterpret_cast<uint4 const*>(base + off);
+            out[0] = t.x;
+            out[1] = t.y;
+            out[2] = t.z;
+            out[3] = t.w;
+        }
+        static __device__ __forceinline__ vi ld_i32(int const* base, vu off) { return *reinterpret_cast<int const*>(reinterpret_cast<char const*>(base) + off); }
+        static __device__ __forceinline__ void st(char* base, vu off, vd v) { *reinterpret_cast<double*>(base + off) = v; }
+        template <class F>
+        static __device__ __forceinline__ void when(vm mask, F&& body)  // one exec region for all the stores of `body`
+        {
+            if(mask) body();
+        }
+        template <class T>
+        static __device__ __forceinline__ T sel(vm m, T a, T b)
+        {
+            return m ? a : b;
+        }
+        static __device__ __forceinline__ vd rcp(vd d) { return WaveOps{}.rcp(d); }
+        static __device__ __forceinline__ vd fma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
+        static __device__ __forceinline__ vm bad(vd piv) { return piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308); }
+        static __device__ __forceinline__ vm none() { return false; }
+        static __device__ __forceinline__ void flag(int* f, vi idx, int bits, vm mask)
+        {
+            if(mask) atomicOr(f + idx, bits);
+        }
+    };
+
+    // grid = quads x lists, one wavefront each.  Consecutive workgroups go round-robin to the 8 XCDs: the lists are dealt out so
+    // that one XCD works on L / 8 of them -- their shared tables (row tables, child maps, metadata) stay in that XCD's L2.
+    __global__ void __launch_bounds__(64) k_m2_factor_quads(DevView V)
+    {
+        int const n = static_cast<int>(blockIdx.x), L = V.n_parts * V.n_waves;
+        int quad, list;
+        if((L & 7) == 0)
+        {
+            int const lpx = L >> 3;
+            list = (n & 7) * lpx + (n >> 3) % lpx;
+            quad = n / L;
+        }
+        else
+        {
+            list = n % L;
+            quad = n / L;
+        }
+        quad_factor_list<QuadDev>(V, quad, list);
+    }
+
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-function upper bound: raised when a launch needs more than any launch
     // before it, never per launch (a Newton iteration of the split schedule is ~16 launches; engines on several host threads
     // share the table)
@@ -963,6 +1054,8 @@ namespace pe
         {
             // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
             if(ev0) (void)hipEventRecord(ev0, st);
+            // the wave fronts of four instances per wavefront (pe_quad.hpp); k_m2_factor_parts then runs the cooperative fronts only
+            if(V.quad && V.n_quads > 0) hipLaunchKernelGGL(k_m2_factor_quads, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), 0, st, V);
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
             static bool const wide_knob = getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;

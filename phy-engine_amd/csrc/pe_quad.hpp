@@ -1,0 +1,328 @@
+// pe_quad.hpp -- lane-group ("quad") numeric factorisation of the WAVE fronts of the split schedule.
+//
+// Replaces, for the small fronts below the cooperative part of the assembly tree, the per-instance path of pe_front.hpp
+// (front_factor<WaveTeam>) -- i.e. the same slice of Eigen's SparseLU compute()+solve() (circuits/circuit.h:1516-1518) -- with an
+// execution that shares ALL index and control work between instances, the lever the round-2 counters pointed at (every one of the
+// 1 024 instances of a sweep walks the same elimination tree):
+//
+//   * one wavefront = FOUR instances x one list of wave fronts; lane = 16 q + r: instance q of the quad, row r of a row set;
+//   * the whole front lives in REGISTERS: a[s][c] = entry (row r + 16 s, column c) -- fronts of order <= 32 (two row sets), <= 16
+//     pivots (all in row set 0), the right-hand side of the fused forward substitution as one more column g[s];
+//   * every index is wavefront-uniform (scalar loads from the quad plan of pe_symbolic.cpp): which columns a child contributes to,
+//     where a column of the factor / of the update matrix goes; the only per-lane index data are one byte per own entry of A and
+//     one byte per child and row set;
+//   * the pivot row reaches the 16 lanes of its instance by DPP row_newbcast (v_mov_b64_dpp: one instruction per column for all
+//     four instances, no LDS, no v_readlane, no SGPR round trip); rows at or above the pivot take a zero multiplier;
+//   * no LDS at all: occupancy is bound by registers only, every load of a front is independent of every other (one memory
+//     round trip per front instead of index -> value -> LDS chains), lanes without a contribution read a zero region parked
+//     behind each instance's arena instead of branching.
+//
+// Output layout = front_factor's: U11 (with the scaled multipliers below its diagonal) + U12 in the factor store, L21 only when a
+// later launch reuses the factors (V.keep_l21), update matrix + update vector in the arena slot, forward-substituted pivots in w.
+//
+// Written against an execution model X so that tests/emu can run the SAME code on the host with 64-wide vector types
+// (test infrastructure; the product instantiates only the device model of pe_kernels.hip):
+//   X::vd / vi / vu / vm   double / int / unsigned / predicate of one lane (device) or of all 64 lanes (emulation)
+//   X::lane()              lane index 0..63
+//   X::bcast(v, k)         value of lane 16 (lane / 16) + k, k a compile-time constant after unrolling
+//   X::ld / ld_u32x4 / ld_i32 (uniform base, per-lane byte offset), X::st(base, offset, value) inside X::when(mask, body)
+//   X::sel(mask, a, b), X::rcp(d), X::fma(a, b, c), X::bad(piv), X::flag(ptr, index, bits, mask)
+#pragma once
+#include "pe_device.hpp"
+
+#if defined(__HIPCC__)
+    #define PEQ_DEV __device__ __forceinline__
+#else
+    #define PEQ_DEV inline
+#endif
+
+namespace pe
+{
+    template <class X>
+    struct QuadCtx
+    {
+        char const* baseA;             // aval / factor / arena / w of the quad's FIRST instance; the others sit at 32-bit byte offsets from it
+        char* baseF;
+        char* baseR;
+        char* baseW;
+        typename X::vu offA, offF, offR, offW;
+        typename X::vm valid;          // the lane's instance exists and is active (stores only)
+        typename X::vi r;              // lane & 15
+    };
+
+    // this lane's index data of one front (pe_symbolic.hpp, q_lane): per row set the 16 RS table bytes of its row, then 16 child bytes
+    template <class X>
+    struct QuadLaneIdx
+    {
+        typename X::vu w[2][12];
+    };
+    template <class X>
+    PEQ_DEV void quad_lane_idx(QuadLaneIdx<X>& L, unsigned char const* base, int rs, typename X::vi r)
+    {
+        // (requested one front ahead: the loads fly behind the current front's arithmetic)
+        if(rs == 1)
+        {
+            typename X::vu const off = X::to_u(r * 32);
+            X::ld_u32x4(base, off, &L.w[0][0]);
+            X::ld_u32x4(base, off + 16u, &L.w[0][4]);
+#pragma unroll
+            for(int j = 8; j < 12; ++j) L.w[0][j] = typename X::vu(0u);
+#pragma unroll
+            for(int j = 0; j < 12; ++j) L.w[1][j] = typename X::vu(0u);
+        }
+        else
+        {
+#pragma unroll
+            for(int s2 = 0; s2 < 2; ++s2)
+            {
+                typename X::vu const off = X::to_u((r + 16 * s2) * 48);
+#pragma unroll
+                for(int j = 0; j < 3; ++j) X::ld_u32x4(base, off + 16u * j, &L.w[s2][4 * j]);
+            }
+        }
+    }
+
+    // One wave front of four instances.  RS = row sets of 16 rows; columns 0 .. 16 RS - 1.  `blk`: the front's block of the list's
+    // program, `L`: this lane's index data.  Returns the lanes that met a bad pivot.
+    template <class X, int RS>
+    PEQ_DEV typename X::vm quad_front(DevView const& V, QuadCtx<X> const& cx, int const* blk, QuadLaneIdx<X> const& L)
+    {
+        using vd = typename X::vd;
+        using vi = typename X::vi;
+        using vu = typename X::vu;
+        using vm = typename X::vm;
+        constexpr int M = 16 * RS;
+        int const m = blk[0], c0 = blk[2], e0 = blk[3];
+        // (developer timing knobs, PHY_ENGINE_HIP_QUAD bits 1..3: skip the elimination / the stores / the children -- wrong results)
+        int const p = (V.quad & 2) ? 0 : blk[1], nch = (V.quad & 8) ? 0 : blk[4];
+        int const u = m - p;
+        long long const lptr = static_cast<long long>(static_cast<unsigned>(blk[6])) | (static_cast<long long>(blk[7]) << 32);
+        long long const sptr = static_cast<long long>(static_cast<unsigned>(blk[8])) | (static_cast<long long>(blk[9]) << 32);
+        vi const r = cx.r;
+
+        vd a[RS][M];
+        vd g[RS];
+        // ---- own entries of A.  Loads are UNCONDITIONAL inside a group of 8 columns (a lane without an entry re-reads the front's
+        // first entry and drops it): no branch per cell, so the loads of a group -- and, registers permitting, of the next groups --
+        // are in flight together.  Row set 1 holds rows >= 16 >= p: only its pivot COLUMNS can carry entries of A.
+        {
+            // (addresses: one wavefront-uniform 64-bit base per array for the whole kernel + a 32-bit offset per lane -- the uniform
+            //  part of an offset is added on the vector side, one v_add per access, instead of a 64-bit scalar pointer per column)
+            vu const oa = cx.offA + static_cast<unsigned>(e0 - 1) * 8u;  // table byte k >= 1 -> entry e0 + k - 1
+#pragma unroll
+            for(int s2 = 0; s2 < RS; ++s2)
+            {
+#pragma unroll
+                for(int C0 = 0; C0 < M; C0 += 8)
+                {
+                    if(C0 < (s2 == 0 ? m : p))
+                    {
+#pragma unroll
+                        for(int C = C0; C < C0 + 8; ++C)
+                        {
+                            vu const k = (L.w[s2][C >> 2] >> (8 * (C & 3))) & 255u;
+                            vm const has = k != 0u;
+                            vd const v = X::ld(cx.baseA, oa + (X::sel(has, k, vu(1u)) << 3));
+                            a[s2][C] = X::sel(has, v, vd(0.0));
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for(int C = C0; C < C0 + 8; ++C) a[s2][C] = vd(0.0);
+                    }
+                }
+            }
+            // right-hand side of the fused forward substitution: pivot rows from w (children's update vectors below)
+            vm const piv_row = r < p;
+            g[0] = X::sel(piv_row, X::ld(cx.baseW, cx.offW + static_cast<unsigned>(c0) * 8u + (X::to_u(X::sel(piv_row, r, vi(0))) << 3)), vd(0.0));
+            if constexpr(RS > 1) g[1] = vd(0.0);
+        }
+        // ---- children: column C of the front takes column cj(C) of the child's update matrix (uniform), this lane its row ci (a byte
+        // per child and row set).  No branch per column either: a column the child does not touch, and a lane whose row it does not
+        // touch, read the zero region behind the arena -- every load of every child is independent of all the others.
+        vu const zoff = cx.offR + static_cast<unsigned>(V.q_zero_off * 8);
+#pragma unroll
+        for(int grp = 0; grp < 4; ++grp)  // (the child bytes of a row: four to a register)
+        {
+            if(4 * grp < nch)
+            {
+                int const e1 = nch < 4 * grp + 4 ? nch : 4 * grp + 4;
+                for(int e = 4 * grp; e < e1; ++e)
+                {
+                    int const* cb = blk + 16 + e * 16;
+                    int const sp = cb[0], uc = cb[1];
+                    unsigned cm[M / 4];
+#pragma unroll
+                    for(int j = 0; j < M / 4; ++j) cm[j] = static_cast<unsigned>(cb[2 + j]);
+                    vu voff[RS];
+#pragma unroll
+                    for(int s2 = 0; s2 < RS; ++s2)
+                    {
+                        vu const ci = (L.w[s2][M / 4 + grp] >> (8 * (e & 3))) & 255u;
+                        voff[s2] = cx.offR + (X::sel(ci != 0u, ci + static_cast<unsigned>(sp - 1), vu(static_cast<unsigned>(V.q_zero_off))) << 3);
+                    }
+                    unsigned const ucb = static_cast<unsigned>(uc) * 8u;
+#pragma unroll
+                    for(int C0 = 0; C0 < M; C0 += 8)
+                    {
+                        if(C0 < m)
+                        {
+#pragma unroll
+                            for(int C = C0; C < C0 + 8; ++C)
+                            {
+                                unsigned const cj = (cm[C >> 2] >> (8 * (C & 3))) & 255u;
+                                unsigned const shift = (cj ? cj - 1u : 0u) * ucb;
+#pragma unroll
+                                for(int s2 = 0; s2 < RS; ++s2) a[s2][C] = a[s2][C] + X::ld(cx.baseR, (cj ? voff[s2] : zoff) + shift);
+                            }
+                        }
+                    }
+                    unsigned const vshift = static_cast<unsigned>(uc) * ucb;  // the child's update vector sits behind its update matrix
+#pragma unroll
+                    for(int s2 = 0; s2 < RS; ++s2) g[s2] = g[s2] + X::ld(cx.baseR, voff[s2] + vshift);
+                }
+            }
+        }
+        // ---- right-looking elimination of the p pivots (rows of set 0): same operation order as block_step_t of pe_kernels.hip
+        vm bad = X::none();
+#pragma unroll
+        for(int kk = 0; kk < 16; ++kk)
+        {
+            // (guards instead of early exits: a `break` would turn the constant trip count into min(p, 16) and the loop would no
+            //  longer unroll -- the register arrays must be indexed by constants)
+            if(kk < p)
+            {
+            vd const piv = X::bcast(a[0][kk], kk);
+            bad = bad | X::bad(piv);
+            vd const rp = X::rcp(piv);
+            vd lm[RS];
+            {
+                vd const l = a[0][kk] * rp;
+                vm const below = r > kk;
+                lm[0] = X::sel(below, l, vd(0.0));
+                a[0][kk] = X::sel(below, l, a[0][kk]);
+            }
+            if constexpr(RS > 1)
+            {
+                lm[1] = a[1][kk] * rp;  // rows 16.. are below every pivot (rows >= m hold zeros)
+                a[1][kk] = lm[1];
+            }
+#pragma unroll
+            for(int C0 = 0; C0 < M; C0 += 4)
+            {
+                if(C0 + 3 > kk && C0 < m)
+                {
+#pragma unroll
+                    for(int C = C0; C < C0 + 4; ++C)
+                    {
+                        if(C > kk)
+                        {
+                            vd const row = X::bcast(a[0][C], kk);
+#pragma unroll
+                            for(int s2 = 0; s2 < RS; ++s2) a[s2][C] = X::fma(-lm[s2], row, a[s2][C]);
+                        }
+                    }
+                }
+            }
+            vd const grow = X::bcast(g[0], kk);
+#pragma unroll
+            for(int s2 = 0; s2 < RS; ++s2) g[s2] = X::fma(-lm[s2], grow, g[s2]);
+            }
+        }
+        // ---- stores (layout of front_factor): L panel m x p (ld m) -- its top p x p block always, the rows below only when a later
+        // launch runs a separate forward pass --, U panel p x u (ld p) behind it, update matrix u x u (ld u) + update vector, w.
+        // One exec region per group of rows, wavefront-uniform column guards inside.
+        {
+            if(!(V.quad & 4))
+            {
+            unsigned const pf = static_cast<unsigned>(lptr) * 8u, mb = static_cast<unsigned>(m) * 8u, pb = static_cast<unsigned>(p) * 8u, ub = static_cast<unsigned>(u) * 8u;
+            unsigned const pu = pf + static_cast<unsigned>(m) * pb;
+            unsigned const ps = static_cast<unsigned>(sptr) * 8u;
+            vu const fo = cx.offF + (X::to_u(r) << 3);
+            X::when(cx.valid & (r < p),
+                    [&]
+                    {
+#pragma unroll
+                        for(int C = 0; C < M; ++C)
+                        {
+                            if(C < p) X::st(cx.baseF, fo + (pf + static_cast<unsigned>(C) * mb), a[0][C]);
+                            else if(C < m)
+                                X::st(cx.baseF, fo + (pu + static_cast<unsigned>(C - p) * pb), a[0][C]);
+                        }
+                        X::st(cx.baseW, cx.offW + static_cast<unsigned>(c0) * 8u + (X::to_u(r) << 3), g[0]);
+                    });
+#pragma unroll
+            for(int s2 = 0; s2 < RS; ++s2)
+            {
+                vi const R = r + 16 * s2;
+                vu const so = cx.offR + (X::to_u(R - p) << 3) + ps;
+                X::when(cx.valid & (R >= p) & (R < m),
+                        [&]
+                        {
+#pragma unroll
+                            for(int C = 0; C < M; ++C)
+                                if(C >= p && C < m) X::st(cx.baseR, so + static_cast<unsigned>(C - p) * ub, a[s2][C]);
+                            X::st(cx.baseR, so + static_cast<unsigned>(u) * ub, g[s2]);
+                            if(V.keep_l21)  // L21: the multipliers below the pivot block, read by a separate forward pass only
+                            {
+                                vu const lo = cx.offF + (X::to_u(R) << 3) + pf;
+#pragma unroll
+                                for(int C = 0; C < 16; ++C)
+                                    if(C < p) X::st(cx.baseF, lo + static_cast<unsigned>(C) * mb, a[s2][C]);
+                            }
+                        });
+            }
+            }
+        }
+        return bad;
+    }
+
+    // One wavefront: quad `quad` (four instances of V.q_list) x wave-front list `list` (0 .. n_parts * n_waves - 1).
+    template <class X>
+    PEQ_DEV void quad_factor_list(DevView const& V, int quad, int list)
+    {
+        using vi = typename X::vi;
+        using vu = typename X::vu;
+        using vm = typename X::vm;
+        int const* ql = V.q_list + static_cast<long long>(quad) * 4;
+        int const b0 = ql[0];
+        vi const lane = X::lane();
+        vi const q = lane >> 4;
+        vi const b = X::ld_i32(ql, X::to_u(q) << 2);
+        QuadCtx<X> cx;
+        cx.valid = b >= 0;
+        vi const bb = X::sel(cx.valid, b, vi(b0));
+        vu const d = X::to_u(bb - b0);  // the host packs a quad so that (d + 1) * stride < 2^32 for every array
+        cx.r = lane & 15;
+        cx.offA = d * static_cast<unsigned>(V.nnzA * 8ll);
+        cx.offF = d * static_cast<unsigned>(V.factor_doubles * 8ll);
+        cx.offR = d * static_cast<unsigned>(V.arena_doubles * 8ll);
+        cx.offW = d * static_cast<unsigned>(V.rows * 8ll);
+        cx.baseA = reinterpret_cast<char const*>(V.aval + static_cast<long long>(b0) * V.nnzA);
+        cx.baseF = reinterpret_cast<char*>(V.factor + static_cast<long long>(b0) * V.factor_doubles);
+        cx.baseR = reinterpret_cast<char*>(V.arena + static_cast<long long>(b0) * V.arena_doubles);
+        cx.baseW = reinterpret_cast<char*>(V.w + static_cast<long long>(b0) * V.rows);
+        int const* lp = V.q_lists + 2 * list;
+        int const* blk = V.q_prog + lp[0];
+        int const nfr = lp[1];
+        vm bad = X::none();
+        if(nfr > 0)
+        {
+            QuadLaneIdx<X> cur;
+            quad_lane_idx<X>(cur, V.q_lane + blk[10], blk[5], cx.r);
+            for(int i = 0; i < nfr; ++i)
+            {
+                int const rs = blk[5], nch = blk[4], rs_next = blk[11];
+                QuadLaneIdx<X> nxt;  // (the last front of a list loads its own data again: no conditional copy of the register block)
+                quad_lane_idx<X>(nxt, V.q_lane + (rs_next ? blk[12] : blk[10]), rs_next ? rs_next : rs, cx.r);
+                if(rs == 1) bad = bad | quad_front<X, 1>(V, cx, blk, cur);
+                else
+                    bad = bad | quad_front<X, 2>(V, cx, blk, cur);
+                cur = nxt;
+                blk += 16 * (1 + nch);
+            }
+        }
+        X::flag(V.flags, bb, 4, bad & cx.valid & (cx.r == 0));
+    }
+}  // namespace pe

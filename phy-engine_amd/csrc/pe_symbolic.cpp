@@ -363,6 +363,8 @@ namespace pe
         }
     }  // namespace
 
+    void build_quad_plan(Symbolic& S);
+
     bool analyze(int n, int const* rp, int const* ci, double const* vals, SymbolicOptions const& opt, Symbolic& S)
     {
         S = Symbolic{};
@@ -770,7 +772,9 @@ namespace pe
             cost[s] = 400.0 + m * m * (2.0 + S.f_p[s]);
             total += cost[s];
             fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
-            if(fits[s] && opt.wave_slot > 0)
+            // lane-group kernel (pe_quad.hpp): two row sets of 16, pivots in the first, one-byte entry indices
+            if(opt.quad) fits[s] = fits[s] && m <= 32 && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
+            if(fits[s] && opt.wave_slot > 0 && !opt.quad)
             {
                 // (the slot also holds the right-hand-side column: m doubles behind the image / the panels)
                 long long const mm = S.f_p[s] + S.f_u[s], whole = (pe_ld(static_cast<int>(mm)) + 1LL) * mm,
@@ -993,6 +997,11 @@ namespace pe
                 base += peak[0] + peak[1];
             }
             S.work_doubles = 0;
+            if(opt.quad)
+            {
+                S.q_zero_off = base;  // never written: lanes of the lane-group kernel without a contribution read their zeros here
+                base += Symbolic::Q_ZERO;
+            }
             S.arena_doubles = base;
         }
         // inverse relative maps of every parent front
@@ -1022,7 +1031,75 @@ namespace pe
                 S.f_cnp[a] = np;
             }
         }
+        if(opt.quad) build_quad_plan(S);
         return true;
+    }
+
+    // index program of the lane-group kernel (pe_symbolic.hpp "quad plan"): every wave front has order <= 32, <= 16 pivots, <= 255 own
+    // entries and <= 16 children (the schedule's `fits`), and so has every child of a wave front (wave fronts form whole subtrees)
+    void build_quad_plan(Symbolic& S)
+    {
+        S.quad = 1;
+        S.q_prog.clear();
+        S.q_lane.clear();
+        int const K = std::max(1, S.n_parts), W = static_cast<int>((S.wave_ptr.size() - 1) / K) - 1;
+        S.q_lists.assign(static_cast<size_t>(2) * K * W, 0);
+        for(int part = 0; part < K; ++part)
+            for(int w = 0; w < W; ++w)
+            {
+                int const L = part * W + w, i0 = S.wave_ptr[part * (W + 1) + w], i1 = S.wave_ptr[part * (W + 1) + w + 1];
+                S.q_lists[2 * L] = static_cast<int>(S.q_prog.size());
+                S.q_lists[2 * L + 1] = i1 - i0;
+                size_t prev_hdr = 0;
+                for(int i = i0; i < i1; ++i)
+                {
+                    int const s = S.wave_list[i];
+                    int const p = S.f_p[s], u = S.f_u[s], m = p + u, rs = m <= 16 ? 1 : 2, M = 16 * rs, rec = M + 16;
+                    int const ch0 = S.f_child_ptr[s], nch = S.f_child_ptr[s + 1] - ch0;
+                    size_t const h = S.q_prog.size();
+                    S.q_prog.resize(h + Symbolic::Q_HDR + static_cast<size_t>(nch) * Symbolic::Q_CHILD, 0);
+                    int* q = S.q_prog.data() + h;
+                    size_t const l0 = S.q_lane.size();
+                    S.q_lane.resize(l0 + static_cast<size_t>(M) * rec, 0);
+                    q[0] = m;
+                    q[1] = p;
+                    q[2] = S.f_col0[s];
+                    q[3] = S.f_asm_ptr[s];
+                    q[4] = nch;
+                    q[5] = rs;
+                    q[6] = static_cast<int>(S.f_lptr[s] & 0xffffffffll);
+                    q[7] = static_cast<int>(S.f_lptr[s] >> 32);
+                    q[8] = static_cast<int>(S.f_sptr[s] & 0xffffffffll);
+                    q[9] = static_cast<int>(S.f_sptr[s] >> 32);
+                    q[10] = static_cast<int>(l0);
+                    if(i > i0)
+                    {
+                        S.q_prog[prev_hdr + 11] = rs;
+                        S.q_prog[prev_hdr + 12] = static_cast<int>(l0);
+                    }
+                    prev_hdr = h;
+                    for(int e = S.f_asm_ptr[s]; e < S.f_asm_ptr[s + 1]; ++e)
+                    {
+                        int const r = S.asm_pos[e] >> 16, c = S.asm_pos[e] & 0xffff;
+                        S.q_lane[l0 + static_cast<size_t>(r) * rec + c] = static_cast<unsigned char>(1 + (e - S.f_asm_ptr[s]));
+                    }
+                    for(int a = 0; a < nch; ++a)
+                    {
+                        int const c = S.f_child[ch0 + a];
+                        int* cb = q + Symbolic::Q_HDR + a * Symbolic::Q_CHILD;
+                        cb[0] = static_cast<int>(S.f_sptr[c]);
+                        cb[1] = S.f_u[c];
+                        unsigned char* cm = reinterpret_cast<unsigned char*>(cb + 2);
+                        for(int k = 0; k < S.f_u[c]; ++k)
+                        {
+                            int const l = S.f_rel[S.f_rows_ptr[c] + k];
+                            cm[l] = static_cast<unsigned char>(1 + k);
+                            S.q_lane[l0 + static_cast<size_t>(l) * rec + M + a] = static_cast<unsigned char>(1 + k);
+                        }
+                    }
+                }
+            }
+        S.q_lane.resize(S.q_lane.size() + 64, 0);  // (slack: the prefetch of a row record reads whole 16-byte pieces)
     }
 
     bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team)

@@ -38,6 +38,8 @@ namespace pe
         int n_parts{1};           // > 1: multi-workgroup mode, the tree below the level-1 cut is spread over this many workgroups
         double part_cut{1.5};     // a part subtree may cost at most total / (n_parts * part_cut)
         int shared_cu{};                 // the launch geometry keeps several workgroups per CU (128-VGPR kernel variants)
+        int quad{};                      // 1: the wave fronts run on the lane-group kernel (pe_quad.hpp): order <= 32, <= 16 pivots, <= 255 own entries of A;
+                                         // the symbolic analysis then also builds the quad plan below and pads the arena with a zero region
     long long panel_reserve{384};    // LDS doubles kept free behind the panels of a large front (right-hand-side column, staged child maps)
     long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
@@ -100,6 +102,29 @@ namespace pe
         std::vector<long long> gl_sptr;         // [nfronts + 1]
         std::vector<unsigned short> gl_dst;
         std::vector<int> gl_cnt, gl_src;
+
+        // ---- quad plan (opt.quad): the index "program" of the lane-group kernel for the wave fronts (pe_quad.hpp).  A wavefront handles
+        // FOUR instances (16 lanes each: lane = 16 q + r), the front in registers (row r + 16 s of row set s, every column), all index
+        // data wavefront-uniform.  Wave-front list L (= part * n_waves + wavefront) is a run of blocks in q_prog, fronts in list order:
+        //   q_lists[2 L] first int of the run, q_lists[2 L + 1] fronts in it.
+        // Block of a front = Q_HDR ints, then Q_CHILD ints per child:
+        //   hdr  [0] m  [1] p  [2] first pivot  [3] first own entry of A (f_asm_ptr)  [4] children  [5] row sets RS (1: m <= 16, 2: m <= 32)
+        //        [6,7] f_lptr lo / hi  [8,9] f_sptr lo / hi  [10] byte offset of its per-lane data in q_lane
+        //        [11] RS of the NEXT front of the list (0: none)  [12] byte offset of that front's per-lane data (prefetched one front ahead)
+        //   child [0] its f_sptr (doubles, < 2^31)  [1] its u  [2..9] 32 bytes: [C] = 1 + column of the child's update matrix that lands in
+        //        column C of this front, 0 = none (rows and columns share the map: structurally symmetric fronts)
+        // q_lane, per front 16 RS row records of 16 RS + 16 bytes: [C] (C < 16 RS) = 1 + index (relative to hdr[3]) of the entry of A in
+        // cell (row, C), 0 = none; then [16 RS + e] = 1 + row of child e's update matrix that lands in this row, 0 = none (e < 16).
+        enum : int
+        {
+            Q_HDR = 16,
+            Q_CHILD = 16,
+            Q_ZERO = 1088  // doubles of the zero region behind every instance's arena: where lanes without a contribution read (32 x 32 + 32 + slack)
+        };
+        int quad{};
+        std::vector<int> q_prog, q_lists;
+        std::vector<unsigned char> q_lane;
+        long long q_zero_off{};                 // offset of the zero region in the arena (doubles)
 
         // statistics
         long long nnz_LU{};      // structural nnz(L)+nnz(U) (diagonal counted once) of the supernodal pattern WITHOUT relaxation zeros

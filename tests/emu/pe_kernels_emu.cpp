@@ -7,6 +7,7 @@
 
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
+#include "pe_quad.hpp"
 
 namespace pe
 {
@@ -19,6 +20,18 @@ namespace pe
             return v && *v ? std::atof(v) : 0.0;
         }();
         return (1.0 / d) * (1.0 + eps);
+    }
+
+}  // namespace pe
+#include "quad_emu.hpp"  // (uses emu_rcp)
+namespace pe
+{
+    // the lane-group kernel of the wave fronts, every (quad, list) wavefront one after the other
+    static void emu_factor_quads(DevView const& V)
+    {
+        if(!V.quad) return;
+        for(int quad = 0; quad < V.n_quads; ++quad)
+            for(int list = 0; list < V.n_parts * V.n_waves; ++list) quad_factor_list<QuadEmu>(V, quad, list);
     }
 
     struct SerialTeam
@@ -215,6 +228,14 @@ namespace pe
             else
                 stamp(tm, V, b);
             for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
+        }
+        if(do_factor) emu_factor_quads(V);  // (a launch of its own on the device, between the stamp and the per-instance parts)
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
             if(do_factor)
             {
                 for(int q = 0; q < V.n_parts; ++q)
@@ -267,6 +288,16 @@ namespace pe
             residual_norms(tm, V, b, rr, n4);
             for(int r = 0; r < V.rows; ++r) xs[r] = x[r];
             for(int k = 0; k < V.rows; ++k) w[k] = rr[V.row_src[k]];
+        }
+        emu_factor_quads(V);
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double const* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* xs = V.xsave + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
+            double n4[4];
             for(int q = 0; q < V.n_parts; ++q)
                 if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
             for(int l = 0; l < V.n_top_levels; ++l)
