@@ -20,7 +20,7 @@ namespace pe
     // wavefronts 0..5 of part 0; [32..38] the same six figures (+ own-entries share of the assembly) for the wave fronts of wavefront 0 of part 0; [40..47] factorisation time of parts 0..7
     enum : int
     {
-        PE_PROF = 64
+        PE_PROF = 96  // [64..79] lane-group kernel (pe_quad.hpp), list 0 of the quad that starts at this instance: header wait, assembly, elimination, stores, whole fronts, fronts (count)
     };
 
     // diode parameter columns after host-side prepare_foundation (PN_junction.h:296-354)
@@ -141,7 +141,13 @@ namespace pe
         int quad{};                    // 1: the wave fronts of the split schedule run on k_m2_factor_quads, factor_part skips them
         int const *q_prog{}, *q_lists{};
         unsigned char const* q_lane{};
+        int const *q2_prog{}, *q2_lists{};  // the MID fronts (f_kind 3): second lane-group launch
+        unsigned char const* q2_lane{};
+        int n_mid{};                        // MID fronts per instance (0: no second launch)
+        int const* f_quad{};                // per front: 1 = a wave front the lane-group kernel factors (the per-instance wave phase skips it)
+        int const* f_kind{};                // per front (pe_symbolic.hpp): factor_part skips the MID fronts of its cooperative list
         long long q_zero_off{};        // zero region of every instance's arena (doubles)
+        int q_lds_stride{};            // doubles between the LDS stacks of two instances of a quad (0: no LDS stack); a launch needs 4 x 8 x this bytes
         int const* q_list{};           // [n_quads][4] instances of a quad (-1: none), ascending; all within one 32-bit byte-offset window of [0]
         int n_quads{};
         // ---- Newton

@@ -306,12 +306,21 @@ namespace
         HIPCHK(h, pool.alloc(V.zero, 1));
         // lane-group kernel of the wave fronts (pe_quad.hpp): its tables; V.q_list / V.n_quads follow the `active` mask (upload_active)
         V.quad = 0;
+        V.n_mid = 0;
         if(S.quad)
         {
             HIPCHK(h, pool.upload(V.q_prog, S.q_prog));
             HIPCHK(h, pool.upload(V.q_lists, S.q_lists));
             HIPCHK(h, pool.upload(V.q_lane, S.q_lane));
+            HIPCHK(h, pool.upload(V.q2_prog, S.q2_prog));
+            HIPCHK(h, pool.upload(V.q2_lists, S.q2_lists));
+            HIPCHK(h, pool.upload(V.q2_lane, S.q2_lane));
+            HIPCHK(h, pool.upload(V.f_kind, S.f_kind));
+            HIPCHK(h, pool.upload(V.f_quad, S.f_quad));
+            V.n_mid = S.n_mid;
             V.q_zero_off = S.q_zero_off;
+            // LDS stack of a quad: slot 0 of an instance's stack holds a zero, the stride puts the four instances on different banks
+            V.q_lds_stride = S.q_lds_doubles > 0 ? (S.q_lds_doubles + 1 + 31) / 32 * 32 + 8 : 0;
             // a quad addresses its four instances by 32-bit byte offsets from the first one: every per-instance array must leave room
             // for at least one instance inside 4 GiB (else the wave fronts fall back to the per-instance path of factor_part)
             long long const stride = 8 * std::max({static_cast<long long>(S.nnzA), V.factor_doubles, V.arena_doubles, static_cast<long long>(S.n)});
@@ -382,10 +391,13 @@ namespace
         so.quad = (four_per_cu && large && env_int("PHY_ENGINE_HIP_QUAD", 1) != 0) ? 1 : 0;
         if(so.quad)
         {
-            so.wave_m = 32;
-            so.wave_slot = 0;
-            so.wave_p = 16;
-            so.absorb_m = 32;
+            // (the wave-front class keeps the geometry above: wave fronts that do not qualify for the lane-group kernel -- order 33..45, or
+            //  above one -- stay with the per-instance wave phase, which is cheaper for them than the cooperative phase)
+            so.quad_mid = env_int("PHY_ENGINE_HIP_MID", 0) != 0 ? 1 : 0;  // measured slower than the cooperative phase (pe_quad.hpp): off
+            // update matrices whose parent follows in the same list could stay on an LDS stack: 8 wavefronts per CU (two per SIMD at this
+            // kernel's register count) share the 160 KB -> 600 doubles per instance of a quad
+            // (measured slower than the arena for the fronts it applies to, pe_quad.hpp PE_QUAD_LDS_STACK: off unless asked for)
+            so.quad_lds_doubles = std::max(0, env_int("PHY_ENGINE_HIP_QUAD_STACK", 0));
         }
         so.n_waves = std::clamp(env_int("PHY_ENGINE_HIP_WAVES", so.n_waves), 1, PE_THREADS / 64);
         so.wave_m = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_M", so.wave_m));
@@ -468,10 +480,25 @@ namespace
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
         {
             auto const& S = h->sym;
-            int nk[3]{};
+            int nk[4]{};
             for(int s = 0; s < S.nfronts; ++s) ++nk[S.f_kind[s]];
-            std::fprintf(stderr, "[pe_hip] schedule: %d fronts (%d wave, %d cooperative, %d top), %d parts, %d top levels\n", S.nfronts, nk[0], nk[1],
-                         nk[2], S.n_parts, static_cast<int>(S.top_ptr.size()) - 1);
+            std::fprintf(stderr, "[pe_hip] schedule: %d fronts (%d wave, %d cooperative, %d top, %d mid), %d parts, %d top levels\n", S.nfronts, nk[0], nk[1],
+                         nk[2], nk[3], S.n_parts, static_cast<int>(S.top_ptr.size()) - 1);
+            if(S.quad)
+                std::fprintf(stderr, "[pe_hip]   lane-group kernel: LDS stack %d doubles per instance holds %lld of %lld update-matrix doubles of the wave fronts\n",
+                             S.q_lds_doubles, S.q_lds_kept, S.q_lds_total);
+            if(S.quad)
+            {
+                std::fprintf(stderr, "[pe_hip]   wave-front lists (fronts):");
+                for(size_t L = 0; 2 * L + 1 < S.q_lists.size(); ++L) std::fprintf(stderr, " %d", S.q_lists[2 * L + 1]);
+                std::fprintf(stderr, "\n[pe_hip]   MID lists (fronts):");
+                for(size_t L = 0; 2 * L + 1 < S.q2_lists.size(); ++L) std::fprintf(stderr, " %d", S.q2_lists[2 * L + 1]);
+                std::fprintf(stderr, "\n");
+                for(int s = 0; s < S.nfronts; ++s)
+                    if(S.f_kind[s] == 3 && dump[1] == '4')
+                        std::fprintf(stderr, "[pe_hip]   mid front %d: %dx%d children %d parent %d(kind %d)\n", s, S.f_p[s] + S.f_u[s], S.f_p[s], S.f_child_ptr[s + 1] - S.f_child_ptr[s],
+                                     S.f_parent[s], S.f_parent[s] >= 0 ? S.f_kind[S.f_parent[s]] : -1);
+            }
             for(int kind = 0; kind < 2; ++kind)
             {
                 long long cnt[3]{}, su2[3]{}, spanel[3]{};

@@ -1028,7 +1028,7 @@ namespace pe
         int fail = 0;
         long long const c0 = tm.clock();
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
-        if(!V.quad)  // (quad mode: the wave fronts were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
+        // (quad mode: the wave fronts with V.f_quad were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
         tm.for_each_wave(
             [&](int w, int lane, int NL)
             {
@@ -1036,18 +1036,26 @@ namespace pe
                 double* slot = lds + static_cast<long long>(w) * V.lds_slot;
                 int const q1 = tm.uniform(wp[w + 1]);
                 for(int q = tm.uniform(wp[w]); q < q1; ++q)
-                    if(!front_factor(wt, V, b, V.wave_list[q], slot, V.lds_slot, (w == 0 && part == 0) ? 2 : 0, fuse))
+                {
+                    int const s = tm.uniform(V.wave_list[q]);
+                    if(V.quad && V.f_quad[s]) continue;
+                    if(!front_factor(wt, V, b, s, slot, V.lds_slot, (w == 0 && part == 0) ? 2 : 0, fuse))
                     {
                         fail = 1;
                         break;
                     }
+                }
                 // per-wavefront time of the wave phase (load balance of the static subtree assignment), part 0, wavefronts 0..5
                 if(V.prof && part == 0 && lane == 0 && w < 6) V.prof[b * PE_PROF + 26 + w] += tm.clock() - c0;
             });
         if(tm.sync_or(fail)) return false;
         long long const c1 = tm.clock();
         for(int q = V.coop_ptr[part]; q < V.coop_ptr[part + 1]; ++q)
-            if(!front_factor(tm, V, b, V.coop_list[q], lds, V.lds_doubles - 2, 1, fuse)) return false;
+        {
+            int const s = V.coop_list[q];
+            if(V.quad && V.n_mid > 0 && V.f_kind[s] == 3) continue;  // a MID front: factored by the second lane-group launch (pe_quad.hpp)
+            if(!front_factor(tm, V, b, s, lds, V.lds_doubles - 2, 1, fuse)) return false;
+        }
         if(V.prof && tm.tid() == 0 && part == 0)
         {
             V.prof[b * PE_PROF + 1] += c1 - c0;
@@ -1366,7 +1374,7 @@ namespace pe
     PE_DEV void forward_part(Team const& tm, DevView const& V, int b, int part, double* lds)
     {
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
-        if(!V.quad)  // (quad mode: the wave fronts were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
+        // (quad mode: the wave fronts with V.f_quad were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
         tm.for_each_wave(
             [&](int wv, int lane, int NL)
             {

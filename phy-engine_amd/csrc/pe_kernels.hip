@@ -868,6 +868,9 @@ namespace pe
         if(bits) atomicOr(V.flags + b, bits);
     }
 
+#ifndef PE_QUAD_WAVES
+    #define PE_QUAD_WAVES 2  // wavefronts per SIMD the lane-group kernel is compiled for (<= 256 VGPRs: a front of order 32 alone takes 132)
+#endif
     // ---- lane-group kernel of the wave fronts (pe_quad.hpp): the device execution model.  One lane's view; the 64 lanes of the
     // wavefront run in lockstep under wavefront-uniform control flow, so every cross-lane read is a DPP broadcast inside a row of 16.
     extern "C" __device__ double pe_update_dpp_f64(double, double, int, int, int, bool) __asm("llvm.amdgcn.update.dpp.f64");
@@ -923,6 +926,10 @@ namespace pe
         {
             if(mask) body();
         }
+        // the wavefront's LDS (one wavefront per workgroup): update-matrix stack of the quad
+        static __device__ __forceinline__ vd lds_ld(vu addr) { return *reinterpret_cast<double const*>(reinterpret_cast<char const*>(pe_lds) + addr); }
+        static __device__ __forceinline__ void lds_st(vu addr, vd v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(pe_lds) + addr) = v; }
+        static __device__ __forceinline__ void lds_fence() { WaveOps{}.wave_fence_lds(); }
         template <class T>
         static __device__ __forceinline__ T sel(vm m, T a, T b)
         {
@@ -932,6 +939,17 @@ namespace pe
         static __device__ __forceinline__ vd fma(vd a, vd b, vd c) { return __builtin_fma(a, b, c); }
         static __device__ __forceinline__ vm bad(vd piv) { return piv == 0.0 || !(fabs(piv) <= 1.7976931348623157e308); }
         static __device__ __forceinline__ vm none() { return false; }
+        static __device__ __forceinline__ long long clock() { return static_cast<long long>(wall_clock64()); }
+        static __device__ __forceinline__ long long clock(vd dep)  // read behind the instruction that produced `dep`
+        {
+            asm volatile("" ::"v"(dep));
+            return static_cast<long long>(wall_clock64());
+        }
+        static __device__ __forceinline__ void prof(long long* dst, long long const* v, int n)
+        {
+            if((threadIdx.x & 63) == 0)
+                for(int k = 0; k < n; ++k) dst[k] += v[k];
+        }
         static __device__ __forceinline__ void flag(int* f, vi idx, int bits, vm mask)
         {
             if(mask) atomicOr(f + idx, bits);
@@ -940,7 +958,7 @@ namespace pe
 
     // grid = quads x lists, one wavefront each.  Consecutive workgroups go round-robin to the 8 XCDs: the lists are dealt out so
     // that one XCD works on L / 8 of them -- their shared tables (row tables, child maps, metadata) stay in that XCD's L2.
-    __global__ void __launch_bounds__(64) k_m2_factor_quads(DevView V)
+    __global__ void __launch_bounds__(64, PE_QUAD_WAVES) k_m2_factor_quads(DevView V)
     {
         int const n = static_cast<int>(blockIdx.x), L = V.n_parts * V.n_waves;
         int quad, list;
@@ -956,6 +974,28 @@ namespace pe
             quad = n / L;
         }
         quad_factor_list<QuadDev>(V, quad, list);
+    }
+
+    // the MID fronts of the same quads (row sets up to four, columns in blocks): after the wave fronts, before the cooperative parts
+#ifndef PE_MID_WAVES
+    #define PE_MID_WAVES 2
+#endif
+    __global__ void __launch_bounds__(64, PE_MID_WAVES) k_m2_factor_mid(DevView V)
+    {
+        int const n = static_cast<int>(blockIdx.x), L = V.n_parts * V.n_waves;
+        int quad, list;
+        if((L & 7) == 0)
+        {
+            int const lpx = L >> 3;
+            list = (n & 7) * lpx + (n >> 3) % lpx;
+            quad = n / L;
+        }
+        else
+        {
+            list = n % L;
+            quad = n / L;
+        }
+        quad_factor_mid_list<QuadDev>(V, quad, list);
     }
 
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-function upper bound: raised when a launch needs more than any launch
@@ -1055,7 +1095,18 @@ namespace pe
             // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
             if(ev0) (void)hipEventRecord(ev0, st);
             // the wave fronts of four instances per wavefront (pe_quad.hpp); k_m2_factor_parts then runs the cooperative fronts only
-            if(V.quad && V.n_quads > 0) hipLaunchKernelGGL(k_m2_factor_quads, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), 0, st, V);
+            if(V.quad && V.n_quads > 0)
+            {
+                static int const pad = getenv_int("PHY_ENGINE_HIP_QUAD_LDS", 0);  // developer knob: LDS request that limits the wavefronts per CU
+                size_t const qlds = std::max(static_cast<size_t>(pad), static_cast<size_t>(V.q_lds_stride) * 32);  // four instance stacks
+                if(qlds > 0)
+                {
+                    hipError_t const e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_quads), qlds);
+                    if(e != hipSuccess) return e;
+                }
+                hipLaunchKernelGGL(k_m2_factor_quads, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), qlds, st, V);
+                if(V.n_mid > 0) hipLaunchKernelGGL(k_m2_factor_mid, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), 0, st, V);
+            }
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
             static bool const wide_knob = getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;

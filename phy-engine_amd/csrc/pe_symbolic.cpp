@@ -363,7 +363,7 @@ namespace pe
         }
     }  // namespace
 
-    void build_quad_plan(Symbolic& S);
+    void build_quad_plan(Symbolic& S, int lds_doubles);
 
     bool analyze(int n, int const* rp, int const* ci, double const* vals, SymbolicOptions const& opt, Symbolic& S)
     {
@@ -591,6 +591,8 @@ namespace pe
                 int const mfull = rest + ug;
                 int b;
                 if(mfull <= opt.wave_m) b = a + std::min(rest, opt.wave_p);
+                else if(opt.quad_mid && mfull <= 64)
+                    b = a + std::min(rest, 16);  // a candidate MID front of the lane-group kernels: <= 16 pivots (one row set)
                 else
                 {
                     int pbest = 0;
@@ -764,7 +766,7 @@ namespace pe
         S.f_kind.assign(nf, 1);
         ivec part_of(nf, K > 1 ? -1 : 0);
         std::vector<double> cost(nf, 0.0), sub(nf, 0.0);
-        std::vector<char> fits(nf, 1);
+        std::vector<char> fits(nf, 1), fits_mid(nf, opt.quad_mid ? 1 : 0), fits_quad(nf, opt.quad ? 1 : 0);
         double total = 0.0;
         for(int s = 0; s < nf; ++s)
         {
@@ -773,20 +775,26 @@ namespace pe
             total += cost[s];
             fits[s] = fits[s] && m <= opt.wave_m && S.f_p[s] <= opt.wave_p;
             // lane-group kernel (pe_quad.hpp): two row sets of 16, pivots in the first, one-byte entry indices
-            if(opt.quad) fits[s] = fits[s] && m <= 32 && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
-            if(fits[s] && opt.wave_slot > 0 && !opt.quad)
+            // lane-group kernel (pe_quad.hpp): two row sets of 16, pivots in the first, one-byte entry indices -- a wave front is a QUAD front
+            // when its whole subtree satisfies this; the other wave fronts stay with the per-instance wave phase of factor_part
+            fits_quad[s] = fits_quad[s] && m <= 32 && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
+            if(fits[s] && opt.wave_slot > 0)
             {
                 // (the slot also holds the right-hand-side column: m doubles behind the image / the panels)
                 long long const mm = S.f_p[s] + S.f_u[s], whole = (pe_ld(static_cast<int>(mm)) + 1LL) * mm,
                                 panel = static_cast<long long>(pe_ld(static_cast<int>(mm))) * S.f_p[s] + static_cast<long long>(pe_ld(S.f_p[s])) * S.f_u[s] + mm;
                 if(whole > opt.wave_slot && panel > opt.wave_slot) fits[s] = 0;
             }
+            // MID class of the lane-group kernels: order <= 64 (four row sets), otherwise the wave fronts' limits, whole subtree
+            fits_mid[s] = fits_mid[s] && m <= 64 && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
             sub[s] += cost[s];
             int const P = S.f_parent[s];
             if(P >= 0)
             {
                 sub[P] += sub[s];
                 if(!fits[s]) fits[P] = 0;
+                if(!fits_mid[s]) fits_mid[P] = 0;
+                if(!fits_quad[s]) fits_quad[P] = 0;
             }
         }
         auto mark_subtree = [&](int root, auto&& fn)
@@ -852,9 +860,11 @@ namespace pe
             else
             {
                 double const limit2 = part_total[part_of[s]] / (opt.cut_factor * W);
-                S.f_kind[s] = (fits[s] && sub[s] <= limit2) ? 0 : 1;
+                S.f_kind[s] = (fits[s] && sub[s] <= limit2) ? 0 : (fits_mid[s] ? 3 : 1);
             }
         }
+        S.f_quad.assign(nf, 0);
+        for(int s = 0; s < nf; ++s) S.f_quad[s] = (opt.quad && S.f_kind[s] == 0 && fits_quad[s]) ? 1 : 0;
         // executors: wave w of part q -> q * (W + 1) + w ; cooperative phase of part q -> q * (W + 1) + W ; top fronts: none
         ivec exec_of(nf, -1), wroot_of(nf, -1);
         S.f_wstack.assign(nf, 0);
@@ -889,7 +899,7 @@ namespace pe
             for(int s = 0; s < nf; ++s)
             {
                 if(S.f_kind[s] == 0) exec_of[s] = exec_of[wroot_of[s]];
-                else if(S.f_kind[s] == 1)
+                else if(S.f_kind[s] == 1 || S.f_kind[s] == 3)
                     exec_of[s] = part_of[s] * (W + 1) + W;
             }
         }
@@ -958,7 +968,10 @@ namespace pe
             auto persistent = [&](int s)
             {
                 int const P = S.f_parent[s];
-                return exec_of[s] < 0 || P < 0 || exec_of[P] != exec_of[s];
+                // (a MID front is factored by its own launch, before and in another order than the cooperative list it belongs to:
+                //  its update matrix cannot live on that executor's LIFO stacks)
+                //  its update matrix cannot live on that executor's LIFO stacks; likewise a QUAD front under a wave front of the per-instance path)
+                return exec_of[s] < 0 || P < 0 || exec_of[P] != exec_of[s] || S.f_kind[s] == 3 || (S.f_quad[s] && !S.f_quad[P]);
             };
             for(int s = 0; s < nf; ++s)
                 if(persistent(s))
@@ -1031,75 +1044,144 @@ namespace pe
                 S.f_cnp[a] = np;
             }
         }
-        if(opt.quad) build_quad_plan(S);
+        if(opt.quad) build_quad_plan(S, opt.quad_lds_doubles);
         return true;
     }
 
-    // index program of the lane-group kernel (pe_symbolic.hpp "quad plan"): every wave front has order <= 32, <= 16 pivots, <= 255 own
-    // entries and <= 16 children (the schedule's `fits`), and so has every child of a wave front (wave fronts form whole subtrees)
-    void build_quad_plan(Symbolic& S)
+    // index program of the lane-group kernels (pe_symbolic.hpp "quad plan") for the given lists of fronts (each in postorder).  Every
+    // front has <= 16 pivots, <= 255 own entries and <= 16 children (the schedule's `fits` / `fits_mid`); order <= 32 for the wave
+    // fronts, <= 64 for the MID fronts; and so has every child (whole subtrees).
+    static void build_quad_program(Symbolic& S, std::vector<std::vector<int>> const& lists, int lds_doubles, std::vector<int>& prog, std::vector<int>& lptr,
+                                   std::vector<unsigned char>& lane)
     {
-        S.quad = 1;
-        S.q_prog.clear();
-        S.q_lane.clear();
-        int const K = std::max(1, S.n_parts), W = static_cast<int>((S.wave_ptr.size() - 1) / K) - 1;
-        S.q_lists.assign(static_cast<size_t>(2) * K * W, 0);
-        for(int part = 0; part < K; ++part)
-            for(int w = 0; w < W; ++w)
+        prog.clear();
+        lane.clear();
+        lptr.assign(2 * lists.size(), 0);
+        std::vector<int> lds_off(S.nfronts, -1);
+        for(size_t L = 0; L < lists.size(); ++L)
+        {
+            auto const& lst = lists[L];
+            lptr[2 * L] = static_cast<int>(prog.size());
+            lptr[2 * L + 1] = static_cast<int>(lst.size());
+            size_t prev_hdr = 0;
+            int top = 0;  // LDS stack pointer of this list (doubles per instance)
+            for(size_t i = 0; i < lst.size(); ++i)
             {
-                int const L = part * W + w, i0 = S.wave_ptr[part * (W + 1) + w], i1 = S.wave_ptr[part * (W + 1) + w + 1];
-                S.q_lists[2 * L] = static_cast<int>(S.q_prog.size());
-                S.q_lists[2 * L + 1] = i1 - i0;
-                size_t prev_hdr = 0;
-                for(int i = i0; i < i1; ++i)
+                int const s = lst[i];
+                int const p = S.f_p[s], u = S.f_u[s], m = p + u, rs = (m + 15) / 16, M = 16 * rs, rec = M + 16;
+                int const ch0 = S.f_child_ptr[s], nch = S.f_child_ptr[s + 1] - ch0;
+                size_t const h = prog.size();
+                prog.resize(h + Symbolic::Q_HDR + static_cast<size_t>(nch) * Symbolic::Q_CHILD, 0);
+                int* q = prog.data() + h;
+                size_t const l0 = lane.size();
+                lane.resize(l0 + static_cast<size_t>(M) * rec, 0);
+                q[0] = m;
+                q[1] = p;
+                q[2] = S.f_col0[s];
+                q[3] = S.f_asm_ptr[s];
+                q[4] = nch;
+                q[5] = rs;
+                q[6] = static_cast<int>(S.f_lptr[s] & 0xffffffffll);
+                q[7] = static_cast<int>(S.f_lptr[s] >> 32);
+                q[8] = static_cast<int>(S.f_sptr[s] & 0xffffffffll);
+                q[9] = static_cast<int>(S.f_sptr[s] >> 32);
+                q[10] = static_cast<int>(l0);
                 {
-                    int const s = S.wave_list[i];
-                    int const p = S.f_p[s], u = S.f_u[s], m = p + u, rs = m <= 16 ? 1 : 2, M = 16 * rs, rec = M + 16;
-                    int const ch0 = S.f_child_ptr[s], nch = S.f_child_ptr[s + 1] - ch0;
-                    size_t const h = S.q_prog.size();
-                    S.q_prog.resize(h + Symbolic::Q_HDR + static_cast<size_t>(nch) * Symbolic::Q_CHILD, 0);
-                    int* q = S.q_prog.data() + h;
-                    size_t const l0 = S.q_lane.size();
-                    S.q_lane.resize(l0 + static_cast<size_t>(M) * rec, 0);
-                    q[0] = m;
-                    q[1] = p;
-                    q[2] = S.f_col0[s];
-                    q[3] = S.f_asm_ptr[s];
-                    q[4] = nch;
-                    q[5] = rs;
-                    q[6] = static_cast<int>(S.f_lptr[s] & 0xffffffffll);
-                    q[7] = static_cast<int>(S.f_lptr[s] >> 32);
-                    q[8] = static_cast<int>(S.f_sptr[s] & 0xffffffffll);
-                    q[9] = static_cast<int>(S.f_sptr[s] >> 32);
-                    q[10] = static_cast<int>(l0);
-                    if(i > i0)
-                    {
-                        S.q_prog[prev_hdr + 11] = rs;
-                        S.q_prog[prev_hdr + 12] = static_cast<int>(l0);
-                    }
-                    prev_hdr = h;
-                    for(int e = S.f_asm_ptr[s]; e < S.f_asm_ptr[s + 1]; ++e)
-                    {
-                        int const r = S.asm_pos[e] >> 16, c = S.asm_pos[e] & 0xffff;
-                        S.q_lane[l0 + static_cast<size_t>(r) * rec + c] = static_cast<unsigned char>(1 + (e - S.f_asm_ptr[s]));
-                    }
-                    for(int a = 0; a < nch; ++a)
+                    // this front consumes its children (the top of the stack, postorder), then parks its own update matrix if its
+                    // parent belongs to the same list and the stack has room
+                    for(int a = nch - 1; a >= 0; --a)
                     {
                         int const c = S.f_child[ch0 + a];
-                        int* cb = q + Symbolic::Q_HDR + a * Symbolic::Q_CHILD;
-                        cb[0] = static_cast<int>(S.f_sptr[c]);
-                        cb[1] = S.f_u[c];
-                        unsigned char* cm = reinterpret_cast<unsigned char*>(cb + 2);
-                        for(int k = 0; k < S.f_u[c]; ++k)
-                        {
-                            int const l = S.f_rel[S.f_rows_ptr[c] + k];
-                            cm[l] = static_cast<unsigned char>(1 + k);
-                            S.q_lane[l0 + static_cast<size_t>(l) * rec + M + a] = static_cast<unsigned char>(1 + k);
-                        }
+                        if(lds_off[c] >= 0) top = lds_off[c];
+                    }
+                    int const need = u * (u + 1), P = S.f_parent[s];
+                    bool const same_list = P >= 0 && std::find(lst.begin(), lst.end(), P) != lst.end();
+                    if(lds_doubles > 0) S.q_lds_total += need;
+                    if(same_list && need > 0 && top + need <= lds_doubles)
+                    {
+                        lds_off[s] = top;
+                        top += need;
+                        S.q_lds_kept += need;
+                    }
+                    q[13] = lds_off[s];
+                }
+                if(i > 0)
+                {
+                    prog[prev_hdr + 11] = rs;
+                    prog[prev_hdr + 12] = static_cast<int>(l0);
+                }
+                prev_hdr = h;
+                for(int e = S.f_asm_ptr[s]; e < S.f_asm_ptr[s + 1]; ++e)
+                {
+                    int const r = S.asm_pos[e] >> 16, c = S.asm_pos[e] & 0xffff;
+                    lane[l0 + static_cast<size_t>(r) * rec + c] = static_cast<unsigned char>(1 + (e - S.f_asm_ptr[s]));
+                }
+                for(int a = 0; a < nch; ++a)
+                {
+                    int const c = S.f_child[ch0 + a];
+                    int* cb = q + Symbolic::Q_HDR + a * Symbolic::Q_CHILD;
+                    cb[0] = static_cast<int>(S.f_sptr[c]);
+                    cb[1] = S.f_u[c];
+                    cb[18] = lds_off[c];
+                    unsigned char* cm = reinterpret_cast<unsigned char*>(cb + 2);
+                    for(int k = 0; k < S.f_u[c]; ++k)
+                    {
+                        int const l = S.f_rel[S.f_rows_ptr[c] + k];
+                        cm[l] = static_cast<unsigned char>(1 + k);
+                        lane[l0 + static_cast<size_t>(l) * rec + M + a] = static_cast<unsigned char>(1 + k);
                     }
                 }
             }
-        S.q_lane.resize(S.q_lane.size() + 64, 0);  // (slack: the prefetch of a row record reads whole 16-byte pieces)
+        }
+        lane.resize(lane.size() + 64, 0);  // (slack: the prefetch of a row record reads whole 16-byte pieces)
+    }
+
+    void build_quad_plan(Symbolic& S, int lds_doubles)
+    {
+        S.quad = 1;
+        S.q_lds_doubles = std::max(0, lds_doubles);
+        S.q_lds_kept = S.q_lds_total = 0;
+        int const K = std::max(1, S.n_parts), W = static_cast<int>((S.wave_ptr.size() - 1) / K) - 1;
+        std::vector<std::vector<int>> lists(static_cast<size_t>(K) * W);
+        for(int part = 0; part < K; ++part)
+            for(int w = 0; w < W; ++w)
+                for(int i = S.wave_ptr[part * (W + 1) + w]; i < S.wave_ptr[part * (W + 1) + w + 1]; ++i)
+                    if(S.f_quad[S.wave_list[i]]) lists[static_cast<size_t>(part) * W + w].push_back(S.wave_list[i]);
+        build_quad_program(S, lists, S.q_lds_doubles, S.q_prog, S.q_lists, S.q_lane);
+        // MID fronts: the subtrees of kind-3 fronts inside a part's cooperative list, dealt out to W lists per part (longest first)
+        S.n_mid = 0;
+        std::vector<std::vector<int>> mlists(static_cast<size_t>(K) * W);
+        for(int part = 0; part < K; ++part)
+        {
+            std::vector<int> roots, root_of(S.nfronts, -1);
+            std::vector<double> cost(S.nfronts, 0.0);
+            for(int i = S.coop_ptr[part + 1] - 1; i >= S.coop_ptr[part]; --i)  // parents before children
+            {
+                int const s = S.coop_list[i];
+                if(S.f_kind[s] != 3) continue;
+                ++S.n_mid;
+                int const P = S.f_parent[s];
+                root_of[s] = (P >= 0 && S.f_kind[P] == 3) ? root_of[P] : s;
+                if(root_of[s] == s) roots.push_back(s);
+                double const m = S.f_p[s] + S.f_u[s];
+                cost[root_of[s]] += 400.0 + m * m * (2.0 + S.f_p[s]);
+            }
+            std::sort(roots.begin(), roots.end(), [&](int a, int b) { return cost[a] != cost[b] ? cost[a] > cost[b] : a < b; });
+            std::vector<double> load(W, 0.0);
+            std::vector<int> list_of(S.nfronts, -1);
+            for(int r: roots)
+            {
+                int const w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
+                load[w] += cost[r];
+                list_of[r] = w;
+            }
+            for(int i = S.coop_ptr[part]; i < S.coop_ptr[part + 1]; ++i)  // (ascending = postorder)
+            {
+                int const s = S.coop_list[i];
+                if(S.f_kind[s] == 3) mlists[static_cast<size_t>(part) * W + list_of[root_of[s]]].push_back(s);
+            }
+        }
+        build_quad_program(S, mlists, 0, S.q2_prog, S.q2_lists, S.q2_lane);
     }
 
     bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team)

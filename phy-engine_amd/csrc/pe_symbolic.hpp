@@ -38,8 +38,10 @@ namespace pe
         int n_parts{1};           // > 1: multi-workgroup mode, the tree below the level-1 cut is spread over this many workgroups
         double part_cut{1.5};     // a part subtree may cost at most total / (n_parts * part_cut)
         int shared_cu{};                 // the launch geometry keeps several workgroups per CU (128-VGPR kernel variants)
-        int quad{};                      // 1: the wave fronts run on the lane-group kernel (pe_quad.hpp): order <= 32, <= 16 pivots, <= 255 own entries of A;
+        int quad{};                      // 1: the wave fronts run on the lane-group kernel (pe_quad.hpp) where order <= 32, <= 16 pivots, <= 255 own entries of A, <= 16 children hold for a whole subtree;
                                          // the symbolic analysis then also builds the quad plan below and pads the arena with a zero region
+        int quad_mid{};                  // 1: fronts of order 33..64 whose subtree qualifies form the MID class (f_kind 3) of a second lane-group launch
+        int quad_lds_doubles{};          // LDS doubles per instance of a wavefront's update-matrix stack (0: every update matrix goes through the arena)
     long long panel_reserve{384};    // LDS doubles kept free behind the panels of a large front (right-hand-side column, staged child maps)
     long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
@@ -72,7 +74,10 @@ namespace pe
         long long arena_doubles{};
         long long work_doubles{};               // (unused)
         long long wave_panel_doubles{};         // largest p*(m+u) of a wave front (LDS doubles of one wavefront's slot)
-        std::vector<int> f_kind;                // 0: wave front, 1: cooperative front of a part, 2: top front
+        std::vector<int> f_kind;                // 0: wave front, 1: cooperative front of a part, 2: top front, 3: MID front (quad mode: a front of a
+                                                // part's cooperative list of order <= 64 whose whole subtree the lane-group kernels can run; factored by
+                                                // the second lane-group launch, the solve passes treat it as a cooperative front)
+        std::vector<int> f_quad;                // 1: a wave front factored by the lane-group kernel (quad mode: order <= 32, <= 16 pivots, ... for its whole subtree)
         std::vector<int> f_wstack, f_wpar;      // wave fronts: offset of their solved vector on the wavefront's backward stack, and their parent's (-1: subtree root)
         int wave_stack{1};                      // doubles of the deepest stack (sum of the front orders along a path inside a wave subtree)
         int n_parts{1};
@@ -111,19 +116,28 @@ namespace pe
         //   hdr  [0] m  [1] p  [2] first pivot  [3] first own entry of A (f_asm_ptr)  [4] children  [5] row sets RS (1: m <= 16, 2: m <= 32)
         //        [6,7] f_lptr lo / hi  [8,9] f_sptr lo / hi  [10] byte offset of its per-lane data in q_lane
         //        [11] RS of the NEXT front of the list (0: none)  [12] byte offset of that front's per-lane data (prefetched one front ahead)
-        //   child [0] its f_sptr (doubles, < 2^31)  [1] its u  [2..9] 32 bytes: [C] = 1 + column of the child's update matrix that lands in
+        //        [13] where its update matrix + vector go: offset (doubles) on the wavefront's LDS stack, or -1: the arena slot f_sptr
+        //   child [0] its f_sptr (doubles, < 2^31)  [1] its u  [18] its LDS stack offset or -1 (= its own hdr[13])  [2..17] 64 bytes (32 used by the wave fronts): [C] = 1 + column of the child's update matrix that lands in
         //        column C of this front, 0 = none (rows and columns share the map: structurally symmetric fronts)
         // q_lane, per front 16 RS row records of 16 RS + 16 bytes: [C] (C < 16 RS) = 1 + index (relative to hdr[3]) of the entry of A in
         // cell (row, C), 0 = none; then [16 RS + e] = 1 + row of child e's update matrix that lands in this row, 0 = none (e < 16).
         enum : int
         {
             Q_HDR = 16,
-            Q_CHILD = 16,
-            Q_ZERO = 1088  // doubles of the zero region behind every instance's arena: where lanes without a contribution read (32 x 32 + 32 + slack)
+            Q_CHILD = 32,   // (child: [2..17] = 64 column bytes for the mid fronts, [18] its LDS stack offset)
+            Q_ZERO = 4224   // doubles of the zero region behind every instance's arena: where lanes without a contribution read (64 x 64 + 64 + slack)
         };
+        // LDS stack: an update matrix whose parent sits in the same list stays on chip when it fits -- lists are walked in postorder, so
+        // the children of a front are always the most recent unconsumed entries (LIFO); q_lds_doubles = doubles of one instance's stack.
         int quad{};
+        int q_lds_doubles{};
+        long long q_lds_kept{}, q_lds_total{};  // doubles of update matrices (+ vectors) of wave fronts kept in LDS / in all (statistics)
         std::vector<int> q_prog, q_lists;
         std::vector<unsigned char> q_lane;
+        // the same for the MID fronts (f_kind 3; row sets 1..4): q2_lists[2 L] / [2 L + 1] for list L = part * n_waves + k
+        std::vector<int> q2_prog, q2_lists;
+        std::vector<unsigned char> q2_lane;
+        int n_mid{};
         long long q_zero_off{};                 // offset of the zero region in the arena (doubles)
 
         // statistics

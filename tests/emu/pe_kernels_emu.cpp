@@ -30,8 +30,12 @@ namespace pe
     static void emu_factor_quads(DevView const& V)
     {
         if(!V.quad) return;
+        QuadEmu::lds().assign(static_cast<size_t>(V.q_lds_stride) * 4 + 1, std::nan(""));  // (every wavefront starts with garbage in LDS)
         for(int quad = 0; quad < V.n_quads; ++quad)
             for(int list = 0; list < V.n_parts * V.n_waves; ++list) quad_factor_list<QuadEmu>(V, quad, list);
+        if(V.n_mid > 0)
+            for(int quad = 0; quad < V.n_quads; ++quad)
+                for(int list = 0; list < V.n_parts * V.n_waves; ++list) quad_factor_mid_list<QuadEmu>(V, quad, list);
     }
 
     struct SerialTeam

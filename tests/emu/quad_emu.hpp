@@ -4,6 +4,8 @@
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
+#include <vector>
 
 namespace pe
 {
@@ -134,6 +136,33 @@ namespace pe
             for(int l = 0; l < 64; ++l)
                 if(m.v[l]) std::memcpy(base + off.v[l], &v.v[l], 8);
         }
+        // the wavefront's LDS (bounds-checked: an out-of-range address aborts the test run)
+        static std::vector<double>& lds()
+        {
+            static thread_local std::vector<double> mem;
+            return mem;
+        }
+        static vd lds_ld(vu const& addr)
+        {
+            vd r;
+            for(int l = 0; l < 64; ++l)
+            {
+                if(addr.v[l] % 8 != 0 || addr.v[l] / 8 >= lds().size()) std::abort();
+                r.v[l] = lds()[addr.v[l] / 8];
+            }
+            return r;
+        }
+        static void lds_st(vu const& addr, vd const& v)
+        {
+            vm const& m = cur();
+            for(int l = 0; l < 64; ++l)
+                if(m.v[l])
+                {
+                    if(addr.v[l] % 8 != 0 || addr.v[l] / 8 >= lds().size()) std::abort();
+                    lds()[addr.v[l] / 8] = v.v[l];
+                }
+        }
+        static void lds_fence() {}
         template <class T>
         static Vec64<T> sel(vm const& m, Vec64<T> const& a, Vec64<T> const& b)
         {
@@ -160,6 +189,12 @@ namespace pe
             return r;
         }
         static vm none() { return vm{false}; }
+        static long long clock() { return 0; }
+        static long long clock(vd const&) { return 0; }
+        static void prof(long long* dst, long long const* v, int n)
+        {
+            for(int k = 0; k < n; ++k) dst[k] += v[k];
+        }
         static void flag(int* f, vi const& idx, int bits, vm const& mask)
         {
             for(int l = 0; l < 64; ++l)
