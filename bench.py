@@ -29,7 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import pe_load  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_GUIDE_COPY_GBS = 6290.0  # ... and the float4 device-to-device copy the guide measured on this part (MI355X_MICROARCH.md:36,296)
 
 
 def bytes_per_iteration(info):
@@ -163,6 +164,30 @@ def single_circuit_numbers(pe, W, dt, device):
         eng.close()
     out["note"] = ("one circuit spread over parts x workgroups + top levels (multi-workgroup schedule, one launch per phase, host Newton "
                    "loop): latency-bound; linear_reuse_factor skips B_factor (stamp + triangular solves only)")
+    return out
+
+
+def shard_rates(pe, W, dt, nonlinear, device, total=1024):
+    """What ONE GPU delivers on the per-GPU share of the sweep at 8 / 4 / 2 GPUs (contiguous blocks of ceil(total / N) instances):
+    instance-steps/s at 128, 256 and 512 instances, each with its own launch geometry.  Outside the timed region; lets a reader
+    project the aggregate (N x rate(total / N)) against the 1-GPU rate without an 8-GPU node -- a projection, not a measurement."""
+    out = {}
+    for n_gpus in (8, 4, 2):
+        B = -(-total // n_gpus)
+        try:
+            deck, r, c = pe.deck.rc_mesh_params(W, W, list(range(1, B + 1)), nonlinear)
+            eng = pe.ffi.Engine(device=device)
+            eng.set_options(g_min=0.0)
+            eng.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
+            eng.reset()
+            eng.analyze_tr(dt, 2)
+            t0 = time.perf_counter()
+            st = eng.analyze_tr(dt, 20)
+            el = time.perf_counter() - t0
+            out[str(B)] = {"instance_steps_per_s": st["steps"] / el, "gpu_ms_per_step": st["gpu_ms"] / 20, "n_parts": eng.info()["n_parts"]}
+            eng.close()
+        except Exception as e:
+            out[str(B)] = {"error": str(e)}
     return out
 
 
@@ -300,15 +325,24 @@ def main():
             # entries those fronts hold.  Duration: HIP events recorded around that launch alone (pe_kernels.hip m2_iteration).
             share = 1.0 - info["nnz_lu_stored_top"] / max(1, info["nnz_lu_stored"])
             dom_bytes_iter = share * (bpi["factor"] + 0.5 * bpi["solve"])
+            # ... of which the bytes these kernels really move: the forward substitution is fused into the factorisation (the
+            # right-hand side rides along as one more column of every front), so the factor panels are NOT read a second time --
+            # the 1/2 B_solve of the SURVEY formula is credit for traffic that does not exist (as the un-moved stamp bytes above)
+            dom_bytes_iter_moved = share * bpi["factor"]
             kernel = "k_m2_factor_parts<%d>" % (4 if info["n_wavefronts"] <= 4 else 2)
+            if info.get("n_quad_fronts", 0) > 0:
+                # round 3: the wave fronts that qualify run four instances per wavefront in their own launch right before -- the
+                # HIP events bracket the pair, the bytes are those of the same fronts as before
+                kernel = "k_m2_factor_quads + " + kernel
         else:
             share = 1.0
-            dom_bytes_iter = bpi["iter"]
+            dom_bytes_iter = dom_bytes_iter_moved = bpi["iter"]
             kernel = "k_tr_steps"
         dom_ms = st["dominant_ms"]
         dom_launches = max(1, st["dominant_launches"])
         dom_bytes = dom_bytes_iter * st["newton_iters"] + (0 if split else bpi["companion_per_step"] * st["steps"])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+        achieved_moved = (dom_bytes_iter_moved * st["newton_iters"] + (0 if split else bpi["companion_per_step"] * st["steps"])) / (dom_ms * 1e-3) / 1e9
         line = {
             "metric": "transient steps/sec (+ Newton iters/sec), 10k-node RC mesh",
             "value": steps_total / el,
@@ -329,6 +363,8 @@ def main():
                        "rows": info["rows"], "nnz_a": info["nnz_a"], "nnz_lu": info["nnz_lu"], "instances_total": total, "instances_rank0": B,
                        "parallelism": f"contiguous blocks of ceil({total}/{world}) instances per GPU, no data-path collective, final statistics all-reduce"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "frac_moved": achieved_moved / HBM_PEAK_GBS, "achieved_moved": achieved_moved,
+                         "frac_note": "frac: SURVEY.md 8d bytes (share x (B_factor + 1/2 B_solve)); frac_moved: without the 1/2 B_solve the fused forward substitution never moves",
                          "traffic": None, "kernel": kernel,
                          "launches": dom_launches, "avg_launch_ms": dom_ms / dom_launches, "bytes_per_launch": dom_bytes / dom_launches,
                          "bytes_per_newton_iter": dom_bytes_iter, "share_of_factor_entries": share,
@@ -338,18 +374,23 @@ def main():
                                         "solve_top x levels/backward_parts/finish per Newton iteration (stamp: x-dependent slots only after the first iteration of a time point)" if split else "resident k_tr_steps"}},
             "reduce_ms": reduce_ms,
             "stats_checksum": float(np.sum(stats[0])),
-            "engine": {k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
+            "engine": dict({k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
+                           stored_over_structural=info["nnz_lu_stored"] / max(1, info["nnz_lu"]), n_wave_fronts=info.get("n_wave_fronts"),
+                           n_quad_fronts=info.get("n_quad_fronts")),
         }
         ceiling = measured_hbm_ceiling(eng) if world == 1 else None
         if isinstance(ceiling, float):
             line["roofline"]["measured_ceiling"] = {"GBps": ceiling, "frac_of_measured": achieved / ceiling,
-                                                    "how": "device-to-device stream copy of 2 GiB by the engine's copy kernel (read + write bytes / HIP-event time), this run"}
+                                                    "guide_copy_GBps": HBM_GUIDE_COPY_GBS, "frac_of_guide_copy": achieved / HBM_GUIDE_COPY_GBS,
+                                                    "how": "device-to-device stream copy of 2 GiB by the engine's copy kernel (contiguous chunk per workgroup, 8 x 16 B "
+                                                           "non-temporal loads in flight per lane; read + write bytes / HIP-event time), this run; guide_copy: the float4 "
+                                                           "copy of MI355X_MICROARCH.md, not reached by any copy shape tried on these boxes (scripts/copy_sweep.hip)"}
         elif ceiling:
             line["roofline"]["measured_ceiling"] = {"GBps": None, "how": ceiling}
         # HBM bytes of the dominant kernel from the PMC counters: OFFLINE figure (rocprofv3 cannot profile the process that prints
         # this line) -- two separate --pmc passes of this same command, corrected with the factors calibrated on this engine's
         # access shapes (scripts/hbm_calib.hip); copied from the committed summary only when it was measured for this configuration
-        tp = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
         if os.path.exists(tp):
             try:
                 tj = json.load(open(tp))
@@ -366,6 +407,12 @@ def main():
             except Exception as e:
                 line["single_circuit"] = {"error": str(e)}
             line["other_configs"] = other_config_numbers(pe, device_index)
+            if scaling == "strong" and total == 1024:
+                sr = shard_rates(pe, W, dt, nonlinear, device_index, total)
+                line["shard_rates"] = sr
+                r128 = sr.get("128", {}).get("instance_steps_per_s")
+                if r128:
+                    line["shard_rates"]["projected_8gpu_over_1gpu"] = 8.0 * r128 / line["value"]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(deck, dt, nonlinear, args.cpu_steps)

@@ -139,6 +139,9 @@ typedef struct pe_hip_info
     int n_wavefronts; /* wavefronts per workgroup of the launch geometry chosen for this batch */
     int lds_bytes;    /* dynamic LDS per workgroup */
     long long nnz_lu_stored_top; /* part of nnz_lu_stored held by the fronts of the top levels (split schedule: k_m2_factor_top / k_m2_solve_top) */
+    int n_wave_fronts;           /* fronts below the cooperative part of the tree (one wavefront each) ... */
+    int n_quad_fronts;           /* ... of which the lane-group kernel k_m2_factor_quads factors (four instances per wavefront); 0: not in use */
+    long long nnz_lu_stored_quad; /* part of nnz_lu_stored held by those fronts */
 } pe_hip_info;
 
 typedef struct pe_hip_run_stats
@@ -240,6 +243,30 @@ int pe_hip_measure_hbm_ceiling(pe_hip_engine* h, size_t bytes, int reps, double*
 int pe_hip_sweep_statistics(pe_hip_engine* h, double* out);
 
 int pe_hip_get_instance_state(pe_hip_engine* h, int first_instance, int count, int* status, long long* steps, long long* iters, double* t);
+
+/* ---- Monte-Carlo / parameter sweep over several GPUs of one node (csrc/pe_sweep.cpp).
+ * Independent instances of ONE topology are the natural shard of this path: the symbolic analysis is replicated per device, the
+ * instances are dealt out in contiguous blocks of ceil(batch / G) per device -- the chunk rule of the reference's only
+ * multi-device code, src/pe_synth_cuda_u64_cones.cu:1894-1904 -- and, like that code's entry points (:1861-1872: extern "C",
+ * device mask first), the device set is a bit mask.  One engine + one host thread per device while a call runs; no exchange
+ * between devices except the final reduction of the per-row statistics (pe_hip_sweep_reduce: combined on the host in device
+ * order, bitwise reproducible).  Tables as pe_hip_load_circuit: batched parameter blocks are [batch][count][ncol] over the
+ * WHOLE sweep.  All calls return pe_hip_status; pe_hip_sweep_last_error(s) is valid until the next call on s (s may be NULL
+ * after a failed create). */
+typedef struct pe_hip_sweep pe_hip_sweep;
+int pe_hip_sweep_create(unsigned device_mask, pe_hip_sweep** out); /* bit d = HIP device d */
+void pe_hip_sweep_destroy(pe_hip_sweep* s);
+const char* pe_hip_sweep_last_error(pe_hip_sweep* s);
+int pe_hip_sweep_devices(pe_hip_sweep* s);
+int pe_hip_sweep_shard(pe_hip_sweep* s, int index, int* device, int* first_instance, int* count); /* block of the index-th device of the mask */
+int pe_hip_sweep_set_options(pe_hip_sweep* s, const pe_hip_options* opt);
+int pe_hip_sweep_load_circuit(pe_hip_sweep* s, int n_nodes, int n_branches, int batch, int n_tables, const pe_hip_device_table* tables);
+int pe_hip_sweep_reset(pe_hip_sweep* s);
+int pe_hip_sweep_operating_point(pe_hip_sweep* s, int mode, pe_hip_run_stats* stats); /* OP / DC / TROP solve of every instance */
+int pe_hip_sweep_run(pe_hip_sweep* s, double dt, int nsteps, pe_hip_run_stats* stats); /* transient steps of every instance; stats: sums, slowest device's times */
+int pe_hip_sweep_reduce(pe_hip_sweep* s, double* out); /* [4][rows]: sum, sum of squares, min, max of the current solution over all instances */
+int pe_hip_sweep_get_solution(pe_hip_sweep* s, int first_instance, int count, double* x);
+int pe_hip_sweep_get_instance_state(pe_hip_sweep* s, int first_instance, int count, int* status, long long* steps, long long* iters, double* t);
 /* iteration count of every step of instance 0 since the last reset (parity with the reference's Newton counts) */
 int pe_hip_get_newton_trace(pe_hip_engine* h, int capacity, int* iters, int* n_out);
 /* last stamped MNA system of one instance (CSR, sorted columns; vals/rhs may be NULL) */

@@ -124,6 +124,8 @@ struct pe_hip_engine
         std::vector<int> b_ptr0, b_src0;  // right-hand-side lists of the AC system (the device copy reads one slot per row)
         int rhs0{};                       // first of the 2N right-hand-side slots of the AC value vector
         std::vector<double> x;            // refined solution [batch][2N]
+        double *d_xacc{}, *d_b0{}, *d_worst{};  // device: accumulated solution, the point's right-hand side, worst backward error (refinement)
+        size_t d_len{};
     } ac;
     std::vector<double> sym_values_override;  // representative |A| values for the row matching (AC engine)
 
@@ -870,12 +872,33 @@ namespace
 
     // `only` != null: a retry of exactly those instances after a rolled-back step -- the companion update of that step has already
     // been applied (update_tr_step precedes the failing solve, circuit.h:246-248), so the first step of the retry skips it
-    int run_m2_tr(pe_hip_engine* h, double dt, int nsteps, int& launches, std::vector<int> const* only = nullptr)
+    // `retry`: the first step's companion update has already been applied (see above); false for a plain subset of the instances
+    int run_m2_tr(pe_hip_engine* h, double dt, int nsteps, int& launches, std::vector<int> const* only = nullptr, bool retry = true)
     {
         M2State S;
         int rc = m2_pull(h, S);
         if(rc != PE_HIP_OK) return rc;
         int const B = h->hc.batch;
+        if(!only)
+        {
+            // The batch is solved in lockstep at ONE time point per launch sequence (sources are evaluated at that t).  Instances that
+            // sit at different time points -- one failed and was rolled back in an earlier call while the others went on -- are
+            // therefore run group by group, each at its own t (a revived instance must not be solved at the group's time).
+            std::vector<double> ts;
+            for(int b = 0; b < B; ++b)
+                if(S.status[b] == PE_HIP_OK && std::find(ts.begin(), ts.end(), S.t[b]) == ts.end()) ts.push_back(S.t[b]);
+            if(ts.size() > 1)
+            {
+                for(double const tg: ts)
+                {
+                    std::vector<int> mask(B, 0);
+                    for(int b = 0; b < B; ++b) mask[b] = (S.status[b] == PE_HIP_OK && S.t[b] == tg) ? 1 : 0;
+                    if(int const grc = run_m2_tr(h, dt, nsteps, launches, &mask, false); grc != PE_HIP_OK) return grc;
+                }
+                return PE_HIP_OK;
+            }
+        }
+        bool const skip_first = only && retry;
         bool const may_reuse = !h->hc.nonlinear && !h->opt.refactor_every_solve && !has_overlay(h);  // (overlay values may change every solve)
         std::vector<int> res;
         for(int s = 0; s < nsteps; ++s)
@@ -890,10 +913,10 @@ namespace
             if(only)  // (a retry of some instances: the others must not be touched by m2_point either)
                 for(int b = 0; b < B; ++b)
                     if(!(*only)[b] && S.status[b] == PE_HIP_OK) S.status[b] = -1000;
-            if(has_overlay(h) && !(only && s == 0))
+            if(has_overlay(h) && !(skip_first && s == 0))
                 if(int const orc = overlay_call(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt); orc != PE_HIP_OK) return orc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
-            if(!(only && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
+            if(!(skip_first && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
             double t_prev = 0.0;
             for(int b = 0; b < B; ++b)
@@ -1065,8 +1088,11 @@ int pe_hip_create(int device, pe_hip_engine** out)
 void pe_hip_destroy(pe_hip_engine* h)
 {
     if(!h) return;
-    if(h->ac.eng) pe_hip_destroy(h->ac.eng);
     (void)hipSetDevice(h->device);
+    if(h->ac.d_xacc) (void)hipFree(h->ac.d_xacc);
+    if(h->ac.d_b0) (void)hipFree(h->ac.d_b0);
+    if(h->ac.d_worst) (void)hipFree(h->ac.d_worst);
+    if(h->ac.eng) pe_hip_destroy(h->ac.eng);
     (void)hipStreamSynchronize(h->stream);
     h->circ_pool.release();
     h->sym_pool.release();
@@ -1173,9 +1199,14 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->active_dev.clear();
     h->singular_rematched = false;
     h->sym_dt = 0.0;
+    h->careful = false;  // (a false alarm on the previous circuit must not pin this one to the host-driven schedule)
+    h->n_refined = h->n_rematched = 0;
     h->sym_pool.release();
     if(h->ac.eng)
     {
+        if(h->ac.d_xacc) (void)hipFree(h->ac.d_xacc);
+        if(h->ac.d_b0) (void)hipFree(h->ac.d_b0);
+        if(h->ac.d_worst) (void)hipFree(h->ac.d_worst);
         pe_hip_destroy(h->ac.eng);
         h->ac = pe_hip_engine::Ac{};
     }
@@ -1333,6 +1364,16 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
         out->n_top_levels = h->V.n_top_levels;
         out->n_wavefronts = h->V.n_waves;
         out->lds_bytes = h->V.lds_doubles * 8;
+        for(int s = 0; s < h->sym.nfronts; ++s)
+        {
+            long long const stored = 2LL * h->sym.f_p[s] * h->sym.f_u[s] + static_cast<long long>(h->sym.f_p[s]) * h->sym.f_p[s];
+            if(h->sym.f_kind[s] == 0) ++out->n_wave_fronts;
+            if(h->V.quad && !h->sym.f_quad.empty() && h->sym.f_quad[s])
+            {
+                ++out->n_quad_fronts;
+                out->nnz_lu_stored_quad += stored;
+            }
+        }
         for(int s = 0; s < h->sym.nfronts; ++s)
             if(h->sym.f_kind[s] == 2) out->nnz_lu_stored_top += 2LL * h->sym.f_p[s] * h->sym.f_u[s] + static_cast<long long>(h->sym.f_p[s]) * h->sym.f_p[s];
         out->n_row_swaps = h->sym.n_row_swaps;
@@ -2003,9 +2044,8 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     bool const stale = A.sym_omega < 0.0 || (omega == 0.0) != (A.sym_omega == 0.0) ||
                        (omega != 0.0 && (omega > 10.0 * A.sym_omega || omega < 0.1 * A.sym_omega));
     if(stale) analyse_here();
-    // host copies of every instance's matrix values and right-hand side (for the residuals of the refinement)
-    int const R2 = ah.rows, nnz2 = static_cast<int>(ah.ci.size());
-    std::vector<double> aval(static_cast<size_t>(B) * nnz2), rhs(static_cast<size_t>(B) * R2);
+    // the right-hand side of every instance goes into its value slots (the device copy of the system gathers it from there)
+    int const R2 = ah.rows;
     auto gather = [&](int const* ptr, int const* src, double const* d, int s)
     {
         double acc = 0.0;
@@ -2015,60 +2055,53 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     for(int b = 0; b < B; ++b)
     {
         double* d = &dv[static_cast<size_t>(b) * ah.dv_len];
-        for(int s = 0; s < nnz2; ++s) aval[static_cast<size_t>(b) * nnz2 + s] = gather(ah.a_ptr.data(), ah.a_src.data(), d, s);
-        for(int r = 0; r < R2; ++r) d[A.rhs0 + r] = rhs[static_cast<size_t>(b) * R2 + r] = gather(A.b_ptr0.data(), A.b_src0.data(), d, r);
+        for(int r = 0; r < R2; ++r) d[A.rhs0 + r] = gather(A.b_ptr0.data(), A.b_src0.data(), d, r);
     }
-    auto solve = [&](std::vector<double>& out) -> int
+    if(A.d_len != static_cast<size_t>(B) * R2)
     {
-        // every AC point is an independent linear solve: no sticky failure state, no history
-        HIPCHK(h, hipMemcpy(A.eng->V.dv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
+        if(A.d_xacc) (void)hipFree(A.d_xacc);
+        if(A.d_b0) (void)hipFree(A.d_b0);
+        A.d_xacc = A.d_b0 = nullptr;
+        A.d_len = static_cast<size_t>(B) * R2;
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&A.d_xacc), A.d_len * sizeof(double)));
+        HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&A.d_b0), A.d_len * sizeof(double)));
+        if(!A.d_worst) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&A.d_worst), sizeof(double)));
+    }
+    auto solve = [&](bool upload) -> int
+    {
+        // every AC point is an independent linear solve: no sticky failure state, no history.  A correction solve keeps the device's
+        // value vector: its right-hand-side slots hold the residual the kernel before wrote there.
+        if(upload) HIPCHK(h, hipMemcpy(A.eng->V.dv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
         HIPCHK(h, hipMemset(A.eng->V.status, 0, static_cast<size_t>(B) * sizeof(int)));
-        int const rc = pe_hip_analyze_dc(A.eng, PE_HIP_MODE_DC, st);
-        if(rc != PE_HIP_OK) return rc;
-        out.resize(static_cast<size_t>(B) * R2);
-        return pe_hip_get_solution(A.eng, 0, B, out.data());
+        return pe_hip_analyze_dc(A.eng, PE_HIP_MODE_DC, st);
     };
-    int rc = solve(A.x);
+    int rc = solve(true);
     if(rc == PE_HIP_ERR_SINGULAR && A.sym_omega != omega)
     {
         analyse_here();
-        rc = solve(A.x);
+        rc = solve(true);
     }
     if(rc != PE_HIP_OK) return fail(h, rc, "analyze_ac: " + A.eng->err);
-    // Iterative refinement (the pivot order is static and the real-equivalent form separates the two halves of a complex
-    // pivot: entries like r_open = 1e12 next to j omega C leave errors far above rounding): r = b - A x on the host in fp64,
-    // A dx = r with the same pivot order, x += dx; at most three rounds, stops once the residual is at rounding level.
-    std::vector<double> dx;
+    // Iterative refinement, on the device (the pivot order is static and the real-equivalent form separates the two halves of a
+    // complex pivot: entries like r_open = 1e12 next to j omega C leave errors far above rounding): r = b - A x in fp64 from the
+    // system as the device assembled it (k_ac_residual), A dx = r with the same pivot order, x += dx (k_ac_accumulate); at most
+    // three rounds, stops once the componentwise backward error is at rounding level.  The host reads one double per round.
+    hipStream_t const es = A.eng->stream;
+    HIPCHK(h, pe::launch_ac_accumulate(es, A.eng->V, A.d_xacc, A.d_b0, true));
     for(int round = 0; round < 3; ++round)
     {
+        HIPCHK(h, pe::launch_ac_residual(es, A.eng->V, A.d_xacc, A.d_b0, A.rhs0, A.d_worst));
         double worst = 0.0;
-        for(int b = 0; b < B; ++b)
-        {
-            double const* av = &aval[static_cast<size_t>(b) * nnz2];
-            double const* xb = &A.x[static_cast<size_t>(b) * R2];
-            double* d = &dv[static_cast<size_t>(b) * ah.dv_len];
-            double bn = 0.0, rn = 0.0;
-            for(int r = 0; r < R2; ++r)
-            {
-                double acc = rhs[static_cast<size_t>(b) * R2 + r], mag = std::fabs(acc);
-                for(int e = ah.rp[r]; e < ah.rp[r + 1]; ++e)
-                {
-                    double const t = av[e] * xb[ah.ci[e]];
-                    acc -= t;
-                    mag += std::fabs(t);
-                }
-                d[A.rhs0 + r] = acc;
-                rn = std::max(rn, std::fabs(acc) / (mag > 0.0 ? mag : 1.0));  // componentwise backward error
-                bn = std::max(bn, mag);
-            }
-            (void)bn;
-            worst = std::max(worst, rn);
-        }
+        HIPCHK(h, hipMemcpyAsync(&worst, A.d_worst, sizeof(double), hipMemcpyDeviceToHost, es));
+        HIPCHK(h, hipStreamSynchronize(es));
         if(!(worst > 4.0e-16)) break;
-        rc = solve(dx);
+        rc = solve(false);
         if(rc != PE_HIP_OK) return fail(h, rc, "analyze_ac (refinement): " + A.eng->err);
-        for(size_t i = 0; i < A.x.size(); ++i) A.x[i] += dx[i];
+        HIPCHK(h, pe::launch_ac_accumulate(es, A.eng->V, A.d_xacc, A.d_b0, false));
     }
+    A.x.resize(A.d_len);
+    HIPCHK(h, hipMemcpyAsync(A.x.data(), A.d_xacc, A.d_len * sizeof(double), hipMemcpyDeviceToHost, es));
+    HIPCHK(h, hipStreamSynchronize(es));
     return PE_HIP_OK;
 }
 

@@ -1488,6 +1488,34 @@ namespace pe
         out4[2] = mx;
         out4[3] = mb;
     }
+    // Refinement residual of a small-signal AC point (pe_engine.cpp pe_hip_analyze_ac; the complex system in real-equivalent form):
+    // r = b0 - A xacc with A as the last stamp assembled it, written into the instance's right-hand-side VALUE SLOTS
+    // dv[rhs0 + row] -- the correction solve that follows gathers its right-hand side from there.  Returns this thread's worst
+    // componentwise backward error |r_i| / (|b_i| + sum_j |a_ij x_j|).
+    template <class Team>
+    PE_DEV double ac_residual(Team const& tm, DevView const& V, int b, double const* xacc_all, double const* b0_all, int rhs0)
+    {
+        double const* a = V.aval + static_cast<long long>(b) * V.nnzA;
+        double const* x = xacc_all + static_cast<long long>(b) * V.rows;
+        double const* b0 = b0_all + static_cast<long long>(b) * V.rows;
+        double* dv = V.dv + static_cast<long long>(b) * V.dv_len;
+        double worst = 0.0;
+        for(int r = tm.tid(); r < V.rows; r += tm.size())
+        {
+            double acc = b0[r], mag = fabs(acc);
+            int const e1 = V.csr_rp[r + 1];
+            for(int e = V.csr_rp[r]; e < e1; ++e)
+            {
+                double const t = a[V.slot_e ? V.slot_e[e] : e] * x[V.csr_ci[e]];
+                acc -= t;
+                mag += fabs(t);
+            }
+            dv[rhs0 + r] = acc;
+            worst = fmax(worst, fabs(acc) / (mag > 0.0 ? mag : 1.0));
+        }
+        return worst;
+    }
+
     PE_DEV double backward_error(double const (&n4)[4])
     {
         double const den = n4[1] * n4[2] + n4[3];

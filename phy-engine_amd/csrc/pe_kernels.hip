@@ -1003,13 +1003,17 @@ namespace pe
     // share the table)
     static hipError_t set_lds(void const* fn, size_t bytes)
     {
+        // (the attribute is per DEVICE: engines on several GPUs in one process each raise it on their own device)
         static std::mutex mu;
-        static std::unordered_map<void const*, size_t> allowed;
+        static std::unordered_map<unsigned long long, size_t> allowed;
+        int dev = 0;
+        if(hipError_t const e = hipGetDevice(&dev); e != hipSuccess) return e;
+        unsigned long long const key = (static_cast<unsigned long long>(reinterpret_cast<uintptr_t>(fn)) * 1000003ull) ^ static_cast<unsigned long long>(dev + 1);
         std::lock_guard<std::mutex> lock(mu);
-        auto it = allowed.find(fn);
+        auto it = allowed.find(key);
         if(it != allowed.end() && bytes <= it->second) return hipSuccess;
         hipError_t const e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
-        if(e == hipSuccess) allowed[fn] = bytes;
+        if(e == hipSuccess) allowed[key] = bytes;
         return e;
     }
 
@@ -1244,25 +1248,71 @@ namespace pe
         return hipGetLastError();
     }
 
-    // ---- on-box HBM ceiling: device-to-device stream copy, 16 B per lane, four loads in flight per lane
+    // ---- small-signal AC: iterative refinement of a frequency point entirely on the device (pe_engine.cpp pe_hip_analyze_ac)
+    __global__ void __launch_bounds__(256) k_ac_residual(DevView V, double const* __restrict__ xacc, double const* __restrict__ b0, int rhs0, double* worst)
+    {
+        int const b = static_cast<int>(blockIdx.y);
+        double const w = WaveOps{}.wave_max(ac_residual(GridTeam{}, V, b, xacc, b0, rhs0));
+        // (non-negative doubles order like their bit patterns; a NaN residual has the largest pattern: the host sees it)
+        if((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(worst), static_cast<unsigned long long>(__double_as_longlong(fabs(w))));
+    }
+    __global__ void __launch_bounds__(256) k_ac_accumulate(DevView V, double* __restrict__ xacc, double* __restrict__ b0, int first)
+    {
+        size_t const n = static_cast<size_t>(V.batch) * V.rows;
+        for(size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        {
+            if(first)
+            {
+                xacc[i] = V.x[i];
+                b0[i] = V.rhs[i];
+            }
+            else
+                xacc[i] += V.x[i];
+        }
+    }
+    hipError_t launch_ac_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, int rhs0, double* worst)
+    {
+        hipError_t const e = hipMemsetAsync(worst, 0, sizeof(double), st);
+        if(e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ac_residual, dim3(grid_per_instance(V), V.batch), dim3(256), 0, st, V, xacc, b0, rhs0, worst);
+        return hipGetLastError();
+    }
+    hipError_t launch_ac_accumulate(hipStream_t st, DevView const& V, double* xacc, double* b0, bool first)
+    {
+        size_t const n = static_cast<size_t>(V.batch) * V.rows;
+        int const g = static_cast<int>(std::min<size_t>(1024, (n + 255) / 256));
+        hipLaunchKernelGGL(k_ac_accumulate, dim3(g > 0 ? g : 1), dim3(256), 0, st, V, xacc, b0, first ? 1 : 0);
+        return hipGetLastError();
+    }
+
+    // ---- on-box HBM ceiling: device-to-device stream copy, 16 B per lane.  Shape from scripts/copy_sweep.hip (round 3): every
+    // workgroup owns a contiguous chunk, eight loads in flight per lane, non-temporal loads and stores -- 5.2-5.3 TB/s on these boxes
+    // (grid-stride with four in flight, round 2: 4.4-4.7; hipMemcpyDtoD: 5.0; the guide's float4 copy: 6.29, MI355X_MICROARCH.md:36)
     using v4f_t = __attribute__((ext_vector_type(4))) float;
     __global__ void __launch_bounds__(256) k_stream_copy(v4f_t const* __restrict__ src, v4f_t* __restrict__ dst, size_t n)
     {
-        size_t const stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-        size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-        for(; i + 3 * stride < n; i += 4 * stride)
+        size_t const per = (n + gridDim.x - 1) / gridDim.x;
+        size_t const lo = per * blockIdx.x, hi = lo + per < n ? lo + per : n;
+        for(size_t base = lo; base < hi; base += 8 * static_cast<size_t>(blockDim.x))
         {
-            v4f_t const a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-            dst[i] = a;
-            dst[i + stride] = b;
-            dst[i + 2 * stride] = c;
-            dst[i + 3 * stride] = d;
+            v4f_t v[8];
+#pragma unroll
+            for(int q = 0; q < 8; ++q)
+            {
+                size_t const i = base + q * blockDim.x + threadIdx.x;
+                if(i < hi) v[q] = __builtin_nontemporal_load(src + i);
+            }
+#pragma unroll
+            for(int q = 0; q < 8; ++q)
+            {
+                size_t const i = base + q * blockDim.x + threadIdx.x;
+                if(i < hi) __builtin_nontemporal_store(v[q], dst + i);
+            }
         }
-        for(; i < n; i += stride) dst[i] = src[i];
     }
     hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes)
     {
-        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 16), dim3(256), 0, st, static_cast<v4f_t const*>(src), static_cast<v4f_t*>(dst), bytes / 16);
+        hipLaunchKernelGGL(k_stream_copy, dim3(256 * 32), dim3(256), 0, st, static_cast<v4f_t const*>(src), static_cast<v4f_t*>(dst), bytes / 16);
         return hipGetLastError();
     }
 

@@ -24,6 +24,11 @@ namespace pe
     hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes);
     // one round of iterative refinement of the active instances' last solve + re-check (residual safety net, pe_front.hpp)
     hipError_t launch_m2_refine(hipStream_t st, DevView const& V);
+    // small-signal AC refinement on the device (pe_front.hpp ac_residual): r = b0 - A xacc of every instance into its right-hand-side
+    // value slots dv[rhs0 ..), *worst (device, one double) = max componentwise backward error over all instances
+    hipError_t launch_ac_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, int rhs0, double* worst);
+    // xacc = first ? x : xacc + x  (every instance; x = the engine's current solution);  first also keeps b0 = the stamped right-hand side
+    hipError_t launch_ac_accumulate(hipStream_t st, DevView const& V, double* xacc, double* b0, bool first);
     // per-row {sum v, sum v^2, min, max} of x over the instances (the payload of the sweep's one exchange step):
     // `partial` holds n_chunks x 4 x rows doubles, `out` 4 x rows (both device memory); deterministic (fixed chunk order)
     hipError_t launch_sweep_statistics(hipStream_t st, DevView const& V, int n_chunks, double* partial, double* out);

@@ -27,6 +27,9 @@ EXPORTS = [
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_measure_hbm_ceiling", "pe_hip_get_safety_net_counters", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
     "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",
+    "pe_hip_sweep_create", "pe_hip_sweep_destroy", "pe_hip_sweep_last_error", "pe_hip_sweep_devices", "pe_hip_sweep_shard", "pe_hip_sweep_set_options",
+    "pe_hip_sweep_load_circuit", "pe_hip_sweep_reset", "pe_hip_sweep_operating_point", "pe_hip_sweep_run", "pe_hip_sweep_reduce", "pe_hip_sweep_get_solution",
+    "pe_hip_sweep_get_instance_state",
 ]
 
 
@@ -50,7 +53,8 @@ class Info(C.Structure):
                 ("tree_depth", C.c_int), ("n_row_swaps", C.c_int), ("factor_flops", C.c_double),
                 ("bytes_per_instance", C.c_longlong), ("n_r", C.c_int), ("n_c", C.c_int), ("n_l", C.c_int), ("n_v", C.c_int),
                 ("n_i", C.c_int), ("n_d", C.c_int), ("nonlinear", C.c_int), ("n_parts", C.c_int), ("n_top_levels", C.c_int),
-                ("n_wavefronts", C.c_int), ("lds_bytes", C.c_int), ("nnz_lu_stored_top", C.c_longlong)]
+                ("n_wavefronts", C.c_int), ("lds_bytes", C.c_int), ("nnz_lu_stored_top", C.c_longlong), ("n_wave_fronts", C.c_int),
+                ("n_quad_fronts", C.c_int), ("nnz_lu_stored_quad", C.c_longlong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -400,3 +404,77 @@ class Engine:
         self._chk(lib().pe_hip_solve_csr_real(self._h, n, len(ci), _ip(rp), _ip(ci), _dp(va), _dp(bb), _dp(x), 1 if copy_pattern else 0,
                                               C.byref(tm)))
         return x, {k: getattr(tm, k) for k, _ in tm._fields_}
+
+
+class Sweep:
+    """Monte-Carlo sweep over the devices of `device_mask` (pe_hip_sweep_*): contiguous instance blocks per device, one engine each."""
+
+    def __init__(self, device_mask=1):
+        l = lib()
+        l.pe_hip_sweep_last_error.restype = C.c_char_p
+        l.pe_hip_sweep_last_error.argtypes = [C.c_void_p]
+        for name in ("pe_hip_sweep_destroy", "pe_hip_sweep_devices", "pe_hip_sweep_reset"):
+            getattr(l, name).argtypes = [C.c_void_p]
+        l.pe_hip_sweep_destroy.restype = None
+        l.pe_hip_sweep_set_options.argtypes = [C.c_void_p, C.POINTER(Options)]
+        l.pe_hip_sweep_load_circuit.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(DeviceTable)]
+        l.pe_hip_sweep_run.argtypes = [C.c_void_p, C.c_double, C.c_int, C.POINTER(RunStats)]
+        l.pe_hip_sweep_operating_point.argtypes = [C.c_void_p, C.c_int, C.POINTER(RunStats)]
+        l.pe_hip_sweep_reduce.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        l.pe_hip_sweep_get_solution.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        l.pe_hip_sweep_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        self._h = C.c_void_p()
+        rc = l.pe_hip_sweep_create(C.c_uint(int(device_mask)), C.byref(self._h))
+        if rc != 0:
+            raise PeHipError(rc, (l.pe_hip_sweep_last_error(None) or b"").decode())
+        self.rows = 0
+        self.batch = 0
+
+    def close(self):
+        if self._h:
+            lib().pe_hip_sweep_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise PeHipError(rc, (lib().pe_hip_sweep_last_error(self._h) or b"").decode())
+
+    def set_options(self, g_min=0.0, refactor_every_solve=1, residual_tol=0.0):
+        o = Options(0.0, 0.0, 0.0, 0.0, g_min, 0, refactor_every_solve, 0.0, residual_tol)
+        self._chk(lib().pe_hip_sweep_set_options(self._h, C.byref(o)))
+
+    def load_deck(self, deck, batch, overrides=None):
+        n_nodes, n_br, tables = deck_tables(deck, batch, overrides, 0)
+        arr = (DeviceTable * max(1, len(tables)))()
+        self._keep = list(tables)
+        for i, (kind, nodes, branch, par, batched) in enumerate(tables):
+            arr[i] = DeviceTable(kind, len(nodes), _ip(nodes), None if branch is None else _ip(branch), _dp(par), batched)
+        self._chk(lib().pe_hip_sweep_load_circuit(self._h, int(n_nodes), int(n_br), int(batch), len(tables), arr))
+        self.rows, self.batch = n_nodes + n_br, batch
+
+    def shards(self):
+        out = []
+        for i in range(lib().pe_hip_sweep_devices(self._h)):
+            d, f, c = C.c_int(), C.c_int(), C.c_int()
+            self._chk(lib().pe_hip_sweep_shard(self._h, i, C.byref(d), C.byref(f), C.byref(c)))
+            out.append((d.value, f.value, c.value))
+        return out
+
+    def reset(self):
+        self._chk(lib().pe_hip_sweep_reset(self._h))
+
+    def run(self, dt, nsteps):
+        st = RunStats()
+        self._chk(lib().pe_hip_sweep_run(self._h, float(dt), int(nsteps), C.byref(st)))
+        return st.asdict()
+
+    def reduce(self):
+        out = np.empty((4, self.rows))
+        self._chk(lib().pe_hip_sweep_reduce(self._h, _dp(out)))
+        return out
+
+    def solution(self, first=0, count=None):
+        count = self.batch - first if count is None else count
+        x = np.empty((count, self.rows))
+        self._chk(lib().pe_hip_sweep_get_solution(self._h, int(first), int(count), _dp(x)))
+        return x

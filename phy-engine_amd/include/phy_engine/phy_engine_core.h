@@ -1634,6 +1634,7 @@ namespace phy_engine
             {
                 for(auto* c: self.overlay_models_)
                     if(!c->ptr->step_changed_tr(self.last_step, dt)) return 1;
+                self.last_step = dt;  // update_tr_step sets it after EVERY step (circuit.h:363-374), not once per analyze()
                 return 0;
             }
             self.overlay_mna_.clear_values_keep_pattern();

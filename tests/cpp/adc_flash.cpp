@@ -114,10 +114,27 @@ int main()
         for(std::size_t i = 0; i < kThresholds; ++i) std::printf("%s%d", i ? ", " : "", static_cast<int>(cmp_nodes[i]->node_information.dn.state));
         std::printf("], \"out\": [");
         for(std::size_t i = 0; i < kLevels; ++i) std::printf("%s%d", i ? ", " : "", static_cast<int>(out_nodes[i]->node_information.dn.state));
-        std::printf("]}%s\n", s < 6 ? "," : "");
+        std::printf("]");
+        // SURVEY.md 8d C4 "additionally TR dt 1e-6 x 10 steps to honour 'transient'": the same sample through the transient analysis
+        // (the ladder is resistive: ten trapezoidal steps must reproduce the DC point), then the digital ticks again
+        c.set_analyze_type(pe::analyze_type::TR);
+        c.get_analyze_setting().tr.t_step = 1e-6;
+        c.get_analyze_setting().tr.t_stop = 1e-5;
+        bool const ok_tr = c.analyze();
+        c.digital_clk();
+        c.digital_clk();
+        c.set_analyze_type(pe::analyze_type::DC);
+        std::printf(", \"tr\": {\"ok\": %d, \"v_vin\": %.17g, \"ladder\": [", ok_tr ? 1 : 0, vin.node_information.an.voltage.real());
+        for(std::size_t i = 1; i <= kLevels; ++i) std::printf("%s%.17g", i > 1 ? ", " : "", n_div[i]->node_information.an.voltage.real());
+        std::printf("], \"cmp\": [");
+        for(std::size_t i = 0; i < kThresholds; ++i) std::printf("%s%d", i ? ", " : "", static_cast<int>(cmp_nodes[i]->node_information.dn.state));
+        std::printf("], \"out\": [");
+        for(std::size_t i = 0; i < kLevels; ++i) std::printf("%s%d", i ? ", " : "", static_cast<int>(out_nodes[i]->node_information.dn.state));
+        std::printf("]}}%s\n", s < 6 ? "," : "");
     }
     // config C4 throughput: the same seven inputs again, 20 rounds, on the now resident circuit -- per sample one
     // set_attribute + analyze() (DC on the device) + two digital ticks on the host; nothing is printed inside the timed loop
+    c.mna_mirror_rows = 0;  // (the host copy of the assembled system after every analyze() is a debugging aid: not part of the timed loop)
     auto const t0{std::chrono::steady_clock::now()};
     int timed = 0;
     for(int round = 0; round < 20 && rc == 0; ++round)

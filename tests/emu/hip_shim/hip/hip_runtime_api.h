@@ -18,7 +18,8 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 
 inline const char* hipGetErrorString(hipError_t) { return "emu error"; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// (PE_EMU_DEVICES: how many 'devices' the emulation reports -- the multi-device sweep entry point is tested over two of them)
+inline hipError_t hipGetDeviceCount(int* n) { char const* v = std::getenv("PE_EMU_DEVICES"); *n = v && *v ? std::atoi(v) : 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }

@@ -324,6 +324,32 @@ namespace pe
         }
         return hipSuccess;
     }
+    hipError_t launch_ac_residual(hipStream_t, DevView const& V, double const* xacc, double const* b0, int rhs0, double* worst)
+    {
+        double w = 0.0;
+        for(int b = 0; b < V.batch; ++b)
+        {
+            double const wb = ac_residual(SerialTeam{1}, V, b, xacc, b0, rhs0);
+            w = (wb > w || wb != wb) ? wb : w;
+        }
+        *worst = w;
+        return hipSuccess;
+    }
+    hipError_t launch_ac_accumulate(hipStream_t, DevView const& V, double* xacc, double* b0, bool first)
+    {
+        size_t const n = static_cast<size_t>(V.batch) * V.rows;
+        for(size_t i = 0; i < n; ++i)
+        {
+            if(first)
+            {
+                xacc[i] = V.x[i];
+                b0[i] = V.rhs[i];
+            }
+            else
+                xacc[i] += V.x[i];
+        }
+        return hipSuccess;
+    }
     hipError_t launch_stream_copy(hipStream_t, void const* src, void* dst, size_t bytes)
     {
         std::memcpy(dst, src, bytes);

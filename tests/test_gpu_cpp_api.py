@@ -75,6 +75,17 @@ def test_adc_mixed_signal_matches_reference(built):
         else:
             assert g["cmp"] == r["cmp"], (g["vin"], g["cmp"], r["cmp"])
             assert g["out"] == r["out"], (g["vin"], g["out"], r["out"])
+        # the transient leg of C4 (TR dt 1e-6 x 10 steps per sample, then the ticks again): same checks
+        gt, rt = g["tr"], r["tr"]
+        assert gt["ok"] == rt["ok"] == 1
+        assert abs(gt["v_vin"] - rt["v_vin"]) <= 1e-12
+        assert max(abs(a - b) for a, b in zip(gt["ladder"], rt["ladder"])) <= 1e-12
+        if on_threshold:
+            exp_cmp = [1 if gt["v_vin"] >= t else 0 for t in gt["ladder"][:15]]
+            assert gt["cmp"] == exp_cmp
+            assert sum(gt["out"]) == 1 and gt["out"].index(1) == sum(exp_cmp)
+        else:
+            assert gt["cmp"] == rt["cmp"] and gt["out"] == rt["out"], (g["vin"], gt, rt)
 
 
 def test_cpp_api_compiles_and_loader_symbols_exported(built, pe):
