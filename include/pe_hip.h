@@ -194,6 +194,15 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
  * Call before pe_hip_load_circuit() (the cells are part of the sparsity pattern); n_cells = n_rhs = 0 with fn = NULL removes it. */
 #define PE_HIP_OVERLAY_STEP 0
 #define PE_HIP_OVERLAY_ITERATE 1
+/*     PE_HIP_OVERLAY_CONVERGED  the iterate x has passed the engine's Newton test: the models' check_convergence hooks are consulted
+ *                             as circult::solve does (circuit.h:950-963) -- return 0 to accept it, PE_HIP_OVERLAY_VETO to iterate again
+ *                             (counts against max_newton like any other iteration); a_values / b_values NULL */
+#define PE_HIP_OVERLAY_CONVERGED 2
+#define PE_HIP_OVERLAY_VETO 2
+/*     PE_HIP_OVERLAY_AC       one small-signal point of pe_hip_analyze_ac (the models' iterate_ac hooks, circuit.h:389-431): t carries
+ *                             omega, x the operating point; a_values holds 2 n_cells doubles -- the real parts of the cells, then the
+ *                             imaginary parts -- and b_values 2 n_rhs likewise */
+#define PE_HIP_OVERLAY_AC 3
 typedef int (*pe_hip_overlay_fn)(void* user, int event, int mode, double t, double dt, const double* x, double* a_values, double* b_values);
 int pe_hip_set_overlay(pe_hip_engine* h, int n_cells, const int* rows, const int* cols, const double* representative, int n_rhs, const int* rhs_rows,
                        int nonlinear, pe_hip_overlay_fn fn, void* user);

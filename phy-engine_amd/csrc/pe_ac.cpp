@@ -17,7 +17,7 @@ namespace pe
         };
     }  // namespace
 
-    bool build_ac_circuit(HostCircuit const& hc, AcCircuit& out)
+    bool build_ac_circuit(HostCircuit const& hc, AcCircuit& out, OverlaySpec const* overlay)
     {
         out = AcCircuit{};
         auto& ac = out.hc;
@@ -105,6 +105,19 @@ namespace pe
             A_set_re(hc.drv_node[k], NN + k, DV_ONE, false);
             A_set_re(NN + k, hc.drv_node[k], DV_ONE, false);
             B_re(NN + k, slot(AcSlot::DRIVE, k), false, true);
+        }
+        if(overlay)  // host-stamped models (circuit.h:1071-1084 calls their iterate_ac hooks): complex += on their registered cells
+        {
+            for(size_t i = 0; i < overlay->rows.size(); ++i)
+            {
+                A_re(overlay->rows[i], overlay->cols[i], slot(AcSlot::OV_A_RE, static_cast<int>(i)), false, false);
+                A_im(overlay->rows[i], overlay->cols[i], slot(AcSlot::OV_A_IM, static_cast<int>(i)), false, false);
+            }
+            for(size_t i = 0; i < overlay->rhs_rows.size(); ++i)
+            {
+                B_re(overlay->rhs_rows[i], slot(AcSlot::OV_B_RE, static_cast<int>(i)), false, false);
+                B_im(overlay->rhs_rows[i], slot(AcSlot::OV_B_IM, static_cast<int>(i)), false, false);
+            }
         }
         for(int i = 0; i < hc.nR(); ++i) G4re(hc.r_a[i], hc.r_b[i], slot(AcSlot::R_G, i));           // no iterate_ac: DC stamp
         for(int i = 0; i < hc.nC(); ++i) G4im(hc.c_a[i], hc.c_b[i], slot(AcSlot::C_W, i));           // capacitor.h AC: j omega C
@@ -416,6 +429,10 @@ namespace pe
                     break;
                 }
                 case AcSlot::DRIVE: v = hc.drv_volt[s.idx]; break;
+                case AcSlot::OV_A_RE: v = op.ov_a[s.idx]; break;
+                case AcSlot::OV_A_IM: v = op.ov_a[op.ov_a.size() / 2 + s.idx]; break;
+                case AcSlot::OV_B_RE: v = op.ov_b[s.idx]; break;
+                case AcSlot::OV_B_IM: v = op.ov_b[op.ov_b.size() / 2 + s.idx]; break;
             }
             out[DV_FIXED + i] = v;
         }

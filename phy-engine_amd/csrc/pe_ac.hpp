@@ -26,7 +26,9 @@ namespace pe
             IAC_RE, IAC_IM,      // generic device idx (IAC): Ip cos / sin(phase)
             KL_W11, KL_W12, KL_W22,  // generic device idx (coupled inductors): omega L1, omega M, omega L2
             N3_0, N3_1,  // MOSFET / BJT aux idx: gds, gm | geq, gm of its last linearisation (dv of the main engine)
-            DRIVE       // digital drive idx: its voltage (circuit.h:1015-1022 stamps it in every mode)
+            DRIVE,      // digital drive idx: its voltage (circuit.h:1015-1022 stamps it in every mode)
+            OV_A_RE, OV_A_IM,  // host-stamp overlay cell idx: real / imaginary part of what the models' iterate_ac hooks stamped there
+            OV_B_RE, OV_B_IM   // ... right-hand-side row idx
         };
         int kind, idx;
     };
@@ -38,7 +40,7 @@ namespace pe
     };
 
     // builds the real-equivalent AC circuit of `hc`
-    bool build_ac_circuit(HostCircuit const& hc, AcCircuit& out);
+    bool build_ac_circuit(HostCircuit const& hc, AcCircuit& out, OverlaySpec const* overlay = nullptr);
 
     // main-engine state the AC values depend on, downloaded once per analyze_ac call
     struct AcOperatingPoint
@@ -46,6 +48,7 @@ namespace pe
         std::vector<double> d_geq;      // [batch][nD]
         std::vector<double> dv;         // [batch][dv_len] of the main engine (MOSFET / BJT linearisations)
         std::vector<int> rl_engaged;    // [batch][nRl]
+        std::vector<double> ov_a, ov_b; // host-stamp overlay at this omega: [n cells] real parts then [n cells] imaginary parts; likewise the rows
     };
 
     // value vector of instance b at omega: out[dv_len of the AC circuit]

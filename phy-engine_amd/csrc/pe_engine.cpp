@@ -191,8 +191,9 @@ namespace
         bool const iter = event == PE_HIP_OVERLAY_ITERATE;
         h->ov_a.assign(static_cast<size_t>(hc.n_ov_a), 0.0);
         h->ov_b.assign(static_cast<size_t>(hc.n_ov_b), 0.0);
-        if(h->overlay_fn(h->overlay_user, event, mode, t, dt, h->ov_x.data(), iter ? h->ov_a.data() : nullptr, iter ? h->ov_b.data() : nullptr) != 0)
-            return fail(h, PE_HIP_ERR_INTERNAL, "host-stamp overlay: a model hook failed");
+        int const orc = h->overlay_fn(h->overlay_user, event, mode, t, dt, h->ov_x.data(), iter ? h->ov_a.data() : nullptr, iter ? h->ov_b.data() : nullptr);
+        if(event == PE_HIP_OVERLAY_CONVERGED && orc == PE_HIP_OVERLAY_VETO) return PE_HIP_OVERLAY_VETO;  // (positive: not a pe_hip_status)
+        if(orc != 0) return fail(h, PE_HIP_ERR_INTERNAL, "host-stamp overlay: a model hook failed");
         if(iter)
         {
             if(hc.n_ov_a) HIPCHK(h, hipMemcpy(h->V.dv + hc.dv_ova, h->ov_a.data(), static_cast<size_t>(hc.n_ov_a) * sizeof(double), hipMemcpyHostToDevice));
@@ -854,7 +855,17 @@ namespace
                 int const f = S.flags[b];
                 if(f & 5) result[b] = PE_HIP_ERR_SINGULAR;
                 else if(!h->hc.nonlinear || !(f & 2))
+                {
+                    // circuit.h:950-963: an iterate that passed the Newton test is still subject to the models' check_convergence
+                    // hooks -- host-stamped models only (the built-in ones have none); a veto costs one more iteration
+                    if(has_overlay(h) && h->hc.nonlinear)
+                    {
+                        int const crc = overlay_call(h, PE_HIP_OVERLAY_CONVERGED, mode, t, last_step);
+                        if(crc == PE_HIP_OVERLAY_VETO) continue;
+                        if(crc != PE_HIP_OK) return crc;
+                    }
                     result[b] = it + 1;
+                }
                 else
                     continue;
                 S.active[b] = 0;
@@ -1983,11 +1994,10 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     if(st) std::memset(st, 0, sizeof(*st));
     auto& hc = h->hc;
     if(hc.rows == 0) return PE_HIP_OK;
-    if(has_overlay(h)) return fail(h, PE_HIP_ERR_ARG, "analyze_ac: host-stamped models (pe_hip_set_overlay) have no small-signal path in this engine");
     auto& A = h->ac;
     if(!A.built)
     {
-        if(!pe::build_ac_circuit(hc, A.circ)) return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: could not build the AC system");
+        if(!pe::build_ac_circuit(hc, A.circ, has_overlay(h) ? &h->overlay : nullptr)) return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: could not build the AC system");
         if(pe_hip_create(h->device, &A.eng) != PE_HIP_OK) return fail(h, PE_HIP_ERR_NO_DEVICE, "analyze_ac: " + std::string(pe_hip_last_error(nullptr)));
         // The right-hand side of the device copy comes from one value slot per row: the host evaluates the sources' lists
         // and, for the refinement steps below, writes residuals there.
@@ -2018,6 +2028,17 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     if(!op.d_geq.empty()) HIPCHK(h, hipMemcpy(op.d_geq.data(), h->V.d_geq, op.d_geq.size() * sizeof(double), hipMemcpyDeviceToHost));
     if(!op.dv.empty()) HIPCHK(h, hipMemcpy(op.dv.data(), h->V.dv, op.dv.size() * sizeof(double), hipMemcpyDeviceToHost));
     if(!op.rl_engaged.empty()) HIPCHK(h, hipMemcpy(op.rl_engaged.data(), h->V.rl_engaged, op.rl_engaged.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if(has_overlay(h))
+    {
+        // host-stamped models: their iterate_ac hooks stamp complex values at this omega around the operating point held in x
+        op.ov_a.assign(2 * static_cast<size_t>(hc.n_ov_a), 0.0);
+        op.ov_b.assign(2 * static_cast<size_t>(hc.n_ov_b), 0.0);
+        h->ov_x.resize(static_cast<size_t>(hc.rows));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
+        if(h->overlay_fn(h->overlay_user, PE_HIP_OVERLAY_AC, PE_HIP_MODE_OP, omega, 0.0, h->ov_x.data(), op.ov_a.data(), op.ov_b.data()) != 0)
+            return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: host-stamp overlay: a model's iterate_ac hook failed");
+    }
     auto const& ah = A.circ.hc;
     std::vector<double> dv(static_cast<size_t>(B) * ah.dv_len);
     for(int b = 0; b < B; ++b) pe::fill_ac_values(hc, A.circ, op, b, omega, h->opt.g_min, r_open_of(h), &dv[static_cast<size_t>(b) * ah.dv_len]);

@@ -210,6 +210,9 @@ namespace phy_engine::model
         pin pins[2]{{{u8"A"}}, {{u8"B"}}};
         // derived by prepare_foundation_define from the public parameters, which it never modifies (PN_junction.h:296-354)
         double Is_eff{}, Isr_eff{}, Ut{}, Uth{}, Bv_eff{};
+        // state of the HOST stamp hooks below (a PN_junction embedded in a host-stamped model, e.g. the body diodes of the
+        // reference's BSIM3v3.2 model; a PN_junction of the netlist itself runs on the device and never touches these)
+        double Ud_last{}, geq{}, Ieq{}, tr_hist_current{}, tr_prev_g{};
     };
     // PN_junction.h:296-354 with the reference's constants (the device derives the same quantities from the table row:
     // pe::diode_derive, pe_circuit.cpp); the public parameters are never modified
@@ -247,6 +250,113 @@ namespace phy_engine::model
         return n < 10 ? names[n] : ::fast_io::u8string_view{};
     }
     inline pin_view generate_pin_view_define(model_reserve_type_t<PN_junction>, PN_junction& m) noexcept { return {m.pins, 2}; }
+
+    // ---- host stamp hooks of the junction, for user models that embed one and stamp it themselves (the netlist-level PN_junction is a
+    // device-table model).  Same arithmetic as the device evaluation of pe_front.hpp (eval_devices / companion_update), i.e.
+    // PN_junction.h:10-16 (limexp), :58-109 (critical-voltage limiting with the breakdown mirror), :358-402, :440-503.
+    namespace details
+    {
+        inline double pn_limexp(double x) noexcept { return x > 50.0 ? ::std::exp(50.0) * (1.0 + (x - 50.0)) : (x < -50.0 ? ::std::exp(-50.0) : ::std::exp(x)); }
+        inline double pn_vlimit(PN_junction const& m, double Ud) noexcept
+        {
+            double const Ute{m.N * m.Ut};
+            bool const mirrored{m.Bv_set && Ud < ::std::fmin(0.0, -m.Bv_eff + 10.0 * Ute)};
+            double const u0{mirrored ? -(Ud + m.Bv_eff) : Ud}, u1{mirrored ? -(m.Ud_last + m.Bv_eff) : m.Ud_last};
+            double uf{u0};
+            if(u0 > m.Uth && ::std::fabs(u0 - u1) > 2.0 * Ute)
+            {
+                if(u1 > 0.0)
+                {
+                    double const arg{(u0 - u1) / Ute};
+                    uf = arg > 0.0 ? u1 + Ute * (2.0 + ::std::log(arg - 2.0)) : u1 - Ute * (2.0 + ::std::log(2.0 - arg));
+                }
+                else
+                    uf = Ute * ::std::log(u0 / Ute);
+            }
+            else if(u0 < 0.0)
+            {
+                double const arg{u1 > 0.0 ? -1.0 - u1 : 2.0 * u1 - 1.0};
+                if(u0 < arg) uf = arg;
+            }
+            return mirrored ? -(uf + m.Bv_eff) : uf;
+        }
+        // conductance g between the pins + current source i0 from pin 0 to pin 1
+        template <class V>
+        inline void pn_norton(PN_junction const& m, ::phy_engine::MNA::MNA& mna, V g, double i0) noexcept
+        {
+            auto const a{m.pins[0].nodes->node_index}, b{m.pins[1].nodes->node_index};
+            mna.G_ref(a, a) += g;
+            mna.G_ref(a, b) -= g;
+            mna.G_ref(b, a) -= g;
+            mna.G_ref(b, b) += g;
+            if(i0 != 0.0)
+            {
+                mna.I_ref(a) -= i0;
+                mna.I_ref(b) += i0;
+            }
+        }
+        inline double pn_vd(PN_junction const& m) noexcept
+        { return m.pins[0].nodes->node_information.an.voltage.real() - m.pins[1].nodes->node_information.an.voltage.real(); }
+    }  // namespace details
+    inline bool iterate_dc_define(model_reserve_type_t<PN_junction>, PN_junction& m, ::phy_engine::MNA::MNA& mna) noexcept
+    {
+        if(!m.pins[0].nodes || !m.pins[1].nodes) return true;
+        double const Ud{details::pn_vlimit(m, details::pn_vd(m))};
+        m.Ud_last = Ud;
+        double const Ute{m.N * m.Ut}, Uter{m.Nr * m.Ut};
+        double Id;
+        if(m.Bv_set && Ud < -m.Bv_eff)
+        {
+            double const e{details::pn_limexp(-(m.Bv_eff + Ud) / Ute)};
+            Id = -m.Is_eff * e;
+            m.geq = m.Is_eff * e / Ute;
+        }
+        else
+        {
+            double e{details::pn_limexp(Ud / Ute)};
+            m.geq = m.Is_eff * e / Ute;
+            Id = m.Is_eff * (e - 1.0);
+            e = details::pn_limexp(Ud / Uter);
+            m.geq += m.Isr_eff * e / Uter;
+            Id += m.Isr_eff * (e - 1.0);
+        }
+        m.Ieq = Id - Ud * m.geq;
+        details::pn_norton(m, mna, m.geq, m.Ieq);
+        return true;
+    }
+    // small signal: the incremental conductance of the last linearisation + the diffusion capacitance tt geq; no source term
+    inline bool iterate_ac_define(model_reserve_type_t<PN_junction>, PN_junction& m, ::phy_engine::MNA::MNA& mna, double omega) noexcept
+    {
+        if(!m.pins[0].nodes || !m.pins[1].nodes) return true;
+        details::pn_norton(m, mna, m.geq, 0.0);
+        double const cd{m.tt * m.geq};
+        if(omega != 0.0 && m.tt > 0.0 && m.geq > 0.0 && cd > 0.0) details::pn_norton(m, mna, ::std::complex<double>{0.0, cd * omega}, 0.0);
+        return true;
+    }
+    inline bool step_changed_tr_define(model_reserve_type_t<PN_junction>, PN_junction& m, double, double nstep) noexcept
+    {
+        if(!m.pins[0].nodes || !m.pins[1].nodes) return true;
+        m.Ud_last = details::pn_vd(m);
+        double const cd{m.tt * m.geq};
+        if(!(nstep > 0.0) || !(m.tt > 0.0) || !(m.geq > 0.0) || !(cd > 0.0))
+        {
+            m.tr_hist_current = 0.0;
+            m.tr_prev_g = 0.0;
+            return true;
+        }
+        double const g_new{2.0 * cd / nstep};
+        m.tr_hist_current = -(g_new + m.tr_prev_g) * m.Ud_last - m.tr_hist_current;
+        m.tr_prev_g = g_new;
+        return true;
+    }
+    inline bool iterate_tr_define(model_reserve_type_t<PN_junction>, PN_junction& m, ::phy_engine::MNA::MNA& mna, double) noexcept
+    {
+        (void)iterate_dc_define(model_reserve_type<PN_junction>, m, mna);
+        if(m.pins[0].nodes && m.pins[1].nodes && m.tr_prev_g != 0.0) details::pn_norton(m, mna, m.tr_prev_g, m.tr_hist_current);
+        return true;
+    }
+    inline bool iterate_trop_define(model_reserve_type_t<PN_junction>, PN_junction& m, ::phy_engine::MNA::MNA& mna) noexcept
+    { return iterate_dc_define(model_reserve_type<PN_junction>, m, mna); }
     inline gpu_table_row pn_row(PN_junction const& m, int pa, int pb, bool tt_in_tr) noexcept
     {
         return {PE_HIP_DIODE, pa, pb, -1, {m.Is, m.N, m.Isr, m.Nr, m.Temp, m.Ibv, m.Bv, m.Bv_set ? 1.0 : 0.0, m.Area, m.tt, tt_in_tr ? 1.0 : 0.0}};

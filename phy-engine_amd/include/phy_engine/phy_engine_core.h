@@ -1406,6 +1406,13 @@ namespace phy_engine
                         size_t_to_branch_p.push_back(bv.branches + i);
                         bv.branches[i].index = branch_counter++;
                     }
+                    // internal nodes of the model follow the netlist's nodes, in model order (circuit.h:533-540)
+                    auto const iv = c->ptr->generate_internal_node_view();
+                    for(::std::size_t i = 0; i < iv.size; ++i)
+                    {
+                        size_t_to_node_p.push_back(iv.nodes + i);
+                        iv.nodes[i].node_index = node_counter++;
+                    }
                     if(c->ptr->get_device_type() == model_device_type::digital)
                     {
                         auto const method = static_cast<unsigned>(c->ptr->get_digital_update_method());
@@ -1630,6 +1637,42 @@ namespace phy_engine
         {
             auto& self = *static_cast<circult*>(user);
             self.scatter_from(x);
+            if(event == PE_HIP_OVERLAY_AC)
+            {
+                // circuit.h:389-431: one solve_once per frequency point with the models' iterate_ac hooks (complex stamps); t = omega
+                self.overlay_mna_.clear_values_keep_pattern();
+                self.overlay_mna_.r_open = self.env.r_open > 0.0 ? self.env.r_open : 1e12;
+                for(auto* c: self.overlay_models_)
+                    if(!c->ptr->iterate_ac(self.overlay_mna_, t)) return 1;
+                ::std::size_t cells{};
+                for(auto const& row: self.overlay_mna_.A) cells += row.size();
+                if(cells != self.overlay_cells_.size() || self.overlay_mna_.Z.size() != self.overlay_rhs_.size())
+                {
+                    self.overlay_failed_ = true;
+                    return 2;
+                }
+                ::std::size_t const nc{self.overlay_cells_.size()}, nr{self.overlay_rhs_.size()};
+                for(::std::size_t i = 0; i < nc; ++i)
+                {
+                    auto const v = self.overlay_mna_.A[self.overlay_cells_[i].first][self.overlay_cells_[i].second];
+                    a_values[i] = v.real();
+                    a_values[nc + i] = v.imag();
+                }
+                for(::std::size_t i = 0; i < nr; ++i)
+                {
+                    auto const v = self.overlay_mna_.Z[self.overlay_rhs_[i]];
+                    b_values[i] = v.real();
+                    b_values[nr + i] = v.imag();
+                }
+                return 0;
+            }
+            if(event == PE_HIP_OVERLAY_CONVERGED)
+            {
+                // circuit.h:950-963: every model may veto an iterate that passed the Newton test
+                for(auto* c: self.overlay_models_)
+                    if(!c->ptr->check_convergence()) return PE_HIP_OVERLAY_VETO;
+                return 0;
+            }
             if(event == PE_HIP_OVERLAY_STEP)
             {
                 for(auto* c: self.overlay_models_)
@@ -1687,6 +1730,28 @@ namespace phy_engine
                 overlay_mna_.clear_values_keep_pattern();
                 if(!overlay_stamp(modes[q], tr_duration)) return overlay_hook_failed(nullptr, "iterate_*_define");
             }
+            // A hook may stamp cells later that the discovery stamp did not produce (a companion that is zero before the first step, a
+            // region of operation the start point is not in): close the pattern over every cell a model CAN reach -- all pairs of its
+            // own rows (pins, internal nodes, branches).  Cells only the closure adds weigh next to nothing in the pivot matching.
+            ::std::vector<::std::pair<::std::size_t, ::std::size_t>> discovered;
+            for(::std::size_t r = 0; r < overlay_mna_.A.size(); ++r)
+                for(auto const& [col, v]: overlay_mna_.A[r]) discovered.emplace_back(r, col);
+            for(auto* c: overlay_models_)
+            {
+                ::std::vector<::std::size_t> own;
+                auto const pv = c->ptr->generate_pin_view();
+                for(::std::size_t i = 0; i < pv.size; ++i)
+                    if(pv.pins[i].nodes && pv.pins[i].nodes->node_index != SIZE_MAX) own.push_back(pv.pins[i].nodes->node_index);
+                auto const iv = c->ptr->generate_internal_node_view();
+                for(::std::size_t i = 0; i < iv.size; ++i) own.push_back(iv.nodes[i].node_index);
+                auto const bv = c->ptr->generate_branch_view();
+                for(::std::size_t i = 0; i < bv.size; ++i) own.push_back(node_counter + bv.branches[i].index);
+                for(auto const r: own)
+                {
+                    for(auto const cc: own) overlay_mna_.A_ref(r, cc) += 0.0;
+                    overlay_mna_.Z_ref(r) += 0.0;
+                }
+            }
             overlay_cells_.clear();
             overlay_rhs_.clear();
             ::std::vector<double> rep;
@@ -1696,7 +1761,8 @@ namespace phy_engine
                     overlay_cells_.emplace_back(r, col);
                     next.ov_rows.push_back(static_cast<int>(r));
                     next.ov_cols.push_back(static_cast<int>(col));
-                    rep.push_back(::std::abs(v) > 0.0 ? ::std::abs(v) : 1.0);
+                    bool const seen = ::std::find(discovered.begin(), discovered.end(), ::std::pair<::std::size_t, ::std::size_t>{r, col}) != discovered.end();
+                    rep.push_back(::std::abs(v) > 0.0 ? ::std::abs(v) : (seen ? 1.0 : 1e-30));
                 }
             for(auto const& [row, v]: overlay_mna_.Z)
             {

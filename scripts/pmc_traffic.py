@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Developer tool: profiles/r02_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/profile_round.sh.
+"""Developer tool: profiles/<tag>_pmc_traffic.json from the two rocprofv3 PMC passes of scripts/profile_round.sh.
 
-  python scripts/pmc_traffic.py gpurun_out/<tag>_fetch gpurun_out/<tag>_write gpurun_out/<tag>_bench.json [kernel substring]
+  TAG=r03 python scripts/pmc_traffic.py gpurun_out/<tag>_fetch gpurun_out/<tag>_write gpurun_out/<tag>_bench.json [kernel substring]
+
+The dominant "kernel" may be a PAIR of launches (round 3: "k_m2_factor_quads + k_m2_factor_parts"): the counters of both are summed
+and divided by the number of pairs (= dispatches of the last one).
 
 Sums FETCH_SIZE / WRITE_SIZE (KiB) over the dispatches of the dominant kernel and divides by their count: HBM bytes per
 launch, the same normalisation as roofline.achieved in bench.py.  FETCH_SIZE / WRITE_SIZE (KiB) are converted with the factors
@@ -11,6 +14,8 @@ import csv, glob, json, os, sys
 fetch_dir, write_dir, bench_json = sys.argv[1:4]
 line = json.loads(open(bench_json).read().strip().splitlines()[-1])
 kernel = sys.argv[4] if len(sys.argv) > 4 else line["roofline"]["kernel"].split("<")[0]
+kernels = [k.strip() for k in kernel.split("+")]
+TAG = os.environ.get("TAG", "r03")
 
 
 def newest(d):
@@ -23,8 +28,11 @@ def total(d, counter):
     s, n = 0.0, 0
     for f in newest(d):
         for row in csv.DictReader(open(f)):
-            if kernel in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            if row["Counter_Name"] != counter:
+                continue
+            if any(k in row["Kernel_Name"] for k in kernels):
                 s += float(row["Counter_Value"])
+            if kernels[-1] in row["Kernel_Name"]:
                 n += 1
     return s, n
 
@@ -47,12 +55,12 @@ out = {
             "for this engine's access shapes on the same kind of box (profiles/r02_hbm_calib.json: FETCH_SIZE reports half of the bytes read)",
 }
 out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
-json.dump(out, open(os.path.join(root, "profiles", "r02_pmc_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(root, "profiles", TAG + "_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 
 
 def slim(d, counter, dst):
-    """profiles/r02_pmc_<counter>.csv: the engine's kernels only, the columns the summary uses."""
+    """profiles/<tag>_pmc_<counter>.csv: the engine's kernels only, the columns the summary uses."""
     cols = ["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
     with open(dst, "w", newline="") as o:
         wr = csv.writer(o)
@@ -63,5 +71,5 @@ def slim(d, counter, dst):
                     wr.writerow([row[c] for c in cols])
 
 
-slim(fetch_dir, "FETCH_SIZE", os.path.join(root, "profiles", "r02_pmc_FETCH_SIZE.csv"))
-slim(write_dir, "WRITE_SIZE", os.path.join(root, "profiles", "r02_pmc_WRITE_SIZE.csv"))
+slim(fetch_dir, "FETCH_SIZE", os.path.join(root, "profiles", TAG + "_pmc_FETCH_SIZE.csv"))
+slim(write_dir, "WRITE_SIZE", os.path.join(root, "profiles", TAG + "_pmc_WRITE_SIZE.csv"))

@@ -1,6 +1,6 @@
 # Runs on the GPU box (gpurun): GPU tests + smoke + the default bench bare, under rocprofv3 kernel trace, and the two PMC
 # traffic passes.  Usage: bash scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R

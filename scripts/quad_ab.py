@@ -28,7 +28,9 @@ outs = {}
 for rep in range(int(os.environ.get("REPS", "1"))):
     for quad in os.environ.get("ARMS", "1,0").split(","):
         out = os.path.join(ROOT, "gpurun_out", f"quad_ab_{quad}.npy")
-        env = dict(os.environ, PHY_ENGINE_HIP_QUAD=quad, OUT=out)
+        env = dict(os.environ, OUT=out)
+        if "PHY_ENGINE_HIP_QUAD" not in os.environ or len(os.environ.get("ARMS", "1,0").split(",")) > 1:
+            env["PHY_ENGINE_HIP_QUAD"] = quad
         subprocess.run([sys.executable, "-c", child], env=env, timeout=600)
         outs[quad] = out
 if len(outs) == 2:

@@ -2,7 +2,7 @@
 R=$GRAFT_REPO_ROOT
 while read -r cfg; do
   [ -z "$cfg" ] && continue
-  echo -n "$cfg: "; env $cfg B=${B:-1024} ARMS=1 timeout -k 10 300 python3 $R/scripts/quad_ab.py 2>&1 | python3 -c "
+  echo -n "$cfg: "; env $cfg B=${B:-1024} ARMS=${ARMS:-1} timeout -k 10 300 python3 $R/scripts/quad_ab.py 2>&1 | python3 -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

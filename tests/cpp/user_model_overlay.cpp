@@ -7,6 +7,9 @@
 //   2. user_capacitor  trapezoidal companion kept inside the model (step_changed_tr_define + iterate_tr_define; open in DC):
 //                      the RC charging curve must follow the built-in capacitor's step for step
 //   3. user_cubic      i = k v^3 (non-linear conductor) against the analytic root of (V - v) / R = k v^3
+//   4. user_picky      the cubic conductor with a check_convergence_define hook that vetoes the first iterate that passes the
+//                      engine's Newton test (circuit.h:950-963: the models are consulted after the node / branch test): exactly one
+//                      extra Newton iteration, same answer
 // exit 0 = pass.
 #include <cmath>
 #include <cstdio>
@@ -93,6 +96,34 @@ namespace user
         double const v{v_of(m.pins[0]) - v_of(m.pins[1])};
         double const g{3.0 * m.k * v * v}, i{m.k * v * v * v};
         stamp_norton(mna, m.pins, g, i - g * v);
+        return true;
+    }
+    // ---- 4. the same conductor, but its own convergence hook vetoes once per analysis
+    struct user_picky
+    {
+        inline static constexpr ::fast_io::u8string_view model_name{u8"UserPicky"};
+        inline static constexpr pm::model_device_type device_type{pm::model_device_type::non_linear};
+        inline static constexpr ::fast_io::u8string_view identification_name{u8"UP"};
+        double k{1e-3};
+        inline static int vetoes_left{1}, asked{};  // (the netlist owns a clone of the model: the test reads these)
+        pm::pin pins[2]{{{u8"A"}}, {{u8"B"}}};
+    };
+    inline pm::pin_view generate_pin_view_define(pm::model_reserve_type_t<user_picky>, user_picky& m) noexcept { return {m.pins, 2}; }
+    inline bool iterate_dc_define(pm::model_reserve_type_t<user_picky>, user_picky& m, mna_t& mna) noexcept
+    {
+        double const v{v_of(m.pins[0]) - v_of(m.pins[1])};
+        double const g{3.0 * m.k * v * v}, i{m.k * v * v * v};
+        stamp_norton(mna, m.pins, g, i - g * v);
+        return true;
+    }
+    inline bool check_convergence_define(pm::model_reserve_type_t<user_picky>, user_picky&) noexcept
+    {
+        ++user_picky::asked;
+        if(user_picky::vetoes_left > 0)
+        {
+            --user_picky::vetoes_left;
+            return false;
+        }
         return true;
     }
 }  // namespace user
@@ -209,6 +240,41 @@ int main()
         {
             std::fprintf(stderr, "user cubic: v=%.12g, expected 1\n", volts(mid));
             failed |= 4;
+        }
+    }
+    {
+        // the same circuit twice: with the plain cubic conductor and with the one whose check_convergence hook vetoes once
+        auto run = [&](auto model, double& v, long long& iters) -> bool
+        {
+            circult c{};
+            c.set_analyze_type(analyze_type::DC);
+            auto& nl{c.get_netlist()};
+            auto& top{create_node(nl)};
+            auto& mid{create_node(nl)};
+            between(nl, VDC{.V = 2.0}, top, nl.ground_node);
+            between(nl, resistance{.r = 1000.0}, top, mid);
+            between(nl, model, mid, nl.ground_node);
+            mid.node_information.an.voltage = 0.5;
+            if(!c.analyze())
+            {
+                std::fprintf(stderr, "user picky: %s\n", c.last_error.c_str());
+                return false;
+            }
+            v = volts(mid);
+            iters = c.last_stats.newton_iters;
+            return true;
+        };
+        double v_plain{}, v_picky{};
+        long long it_plain{}, it_picky{};
+        bool ok = run(user::user_cubic{.k = 1e-3}, v_plain, it_plain);
+        ok = ok && run(user::user_picky{.k = 1e-3}, v_picky, it_picky);
+        int const asked{user::user_picky::asked}, left{user::user_picky::vetoes_left};
+        if(!ok) failed |= 8;
+        else if(it_picky != it_plain + 1 || asked != 2 || left != 0 || std::abs(v_picky - 1.0) > 1e-5)
+        {
+            std::fprintf(stderr, "user picky: %lld iterations against %lld without the hook (expected one more), hook asked %d times, v=%.12g\n", it_picky, it_plain, asked,
+                         v_picky);
+            failed |= 8;
         }
     }
     return failed;
