@@ -141,6 +141,8 @@ namespace pe
         int quad{};                    // 1: the wave fronts of the split schedule run on k_m2_factor_quads, factor_part skips them
         int const *q_prog{}, *q_lists{};
         unsigned char const* q_lane{};
+        int const* q_bprog{};               // backward pass of the quad fronts (pe_symbolic.hpp Q_BACK), lists reversed; 1 in quad_back: in use
+        int quad_back{};
         int const *q2_prog{}, *q2_lists{};  // the MID fronts (f_kind 3): second lane-group launch
         unsigned char const* q2_lane{};
         int n_mid{};                        // MID fronts per instance (0: no second launch)

@@ -309,12 +309,14 @@ namespace
         HIPCHK(h, pool.alloc(V.zero, 1));
         // lane-group kernel of the wave fronts (pe_quad.hpp): its tables; V.q_list / V.n_quads follow the `active` mask (upload_active)
         V.quad = 0;
+        V.quad_back = 0;
         V.n_mid = 0;
         if(S.quad)
         {
             HIPCHK(h, pool.upload(V.q_prog, S.q_prog));
             HIPCHK(h, pool.upload(V.q_lists, S.q_lists));
             HIPCHK(h, pool.upload(V.q_lane, S.q_lane));
+            HIPCHK(h, pool.upload(V.q_bprog, S.q_bprog));
             HIPCHK(h, pool.upload(V.q2_prog, S.q2_prog));
             HIPCHK(h, pool.upload(V.q2_lists, S.q2_lists));
             HIPCHK(h, pool.upload(V.q2_lane, S.q2_lane));
@@ -328,6 +330,7 @@ namespace
             // for at least one instance inside 4 GiB (else the wave fronts fall back to the per-instance path of factor_part)
             long long const stride = 8 * std::max({static_cast<long long>(S.nnzA), V.factor_doubles, V.arena_doubles, static_cast<long long>(S.n)});
             V.quad = stride < (1ll << 31) ? (env_int0("PHY_ENGINE_HIP_QUAD", 1) | 1) : 0;
+            V.quad_back = (V.quad && env_int0("PHY_ENGINE_HIP_QUAD_BACK", 1) != 0) ? 1 : 0;  // the same fronts' backward pass on the lane-group kernel
         }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));

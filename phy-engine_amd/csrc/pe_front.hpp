@@ -1404,6 +1404,7 @@ namespace pe
                 for(int q = tm.uniform(wp[wv + 1]) - 1; q >= q0; --q)
                 {
                     int const sq = tm.uniform(V.wave_list[q]);
+                    if(V.quad_back && V.f_quad[sq]) continue;  // solved by k_m2_backward_quads in the launch after this one (pe_quad.hpp)
                     int const pq = V.f_p[sq], mq = pq + V.f_u[sq];
                     // (every wave front qualifies by construction; the general routine stays as the fallback, followed by the gather
                     // that puts its solved vector on the stack for the children)

@@ -930,6 +930,7 @@ namespace pe
         static __device__ __forceinline__ vd lds_ld(vu addr) { return *reinterpret_cast<double const*>(reinterpret_cast<char const*>(pe_lds) + addr); }
         static __device__ __forceinline__ void lds_st(vu addr, vd v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(pe_lds) + addr) = v; }
         static __device__ __forceinline__ void lds_fence() { WaveOps{}.wave_fence_lds(); }
+        static __device__ __forceinline__ void fence() { WaveOps{}.wave_fence(); }
         template <class T>
         static __device__ __forceinline__ T sel(vm m, T a, T b)
         {
@@ -974,6 +975,25 @@ namespace pe
             quad = n / L;
         }
         quad_factor_list<QuadDev>(V, quad, list);
+    }
+
+    // backward pass of the quad fronts: after k_m2_backward_parts (cooperative + per-instance wave fronts of the parts)
+    __global__ void __launch_bounds__(64, 4) k_m2_backward_quads(DevView V)
+    {
+        int const n = static_cast<int>(blockIdx.x), L = V.n_parts * V.n_waves;
+        int quad, list;
+        if((L & 7) == 0)
+        {
+            int const lpx = L >> 3;
+            list = (n & 7) * lpx + (n >> 3) % lpx;
+            quad = n / L;
+        }
+        else
+        {
+            list = n % L;
+            quad = n / L;
+        }
+        quad_backward_list<QuadDev>(V, quad, list);
     }
 
     // the MID fronts of the same quads (row sets up to four, columns in blocks): after the wave fronts, before the cooperative parts
@@ -1150,6 +1170,7 @@ namespace pe
         }
         else
             hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_b, st, V, 1);
+        if(V.quad_back && V.n_quads > 0) hipLaunchKernelGGL(k_m2_backward_quads, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), 0, st, V);
         if(!do_factor && ev1) (void)hipEventRecord(ev1, st);
         if(!refine)
         {

@@ -29,6 +29,7 @@
 //   X::bcast(v, k)         value of lane 16 (lane / 16) + k, k a compile-time constant after unrolling
 //   X::ld / ld_u32x4 / ld_i32 (uniform base, per-lane byte offset), X::st(base, offset, value) inside X::when(mask, body)
 //   X::lds_ld(byte address) / lds_st(byte address, value) inside X::when / lds_fence(): the wavefront's LDS (update-matrix stack)
+//   X::fence(): the wavefront's earlier global stores are visible to its later loads (other lanes included)
 //   X::sel(mask, a, b), X::rcp(d), X::fma(a, b, c), X::bad(piv), X::flag(ptr, index, bits, mask)
 #pragma once
 #include "pe_device.hpp"
@@ -799,5 +800,118 @@ namespace pe
             blk += 16 + 32 * nch;
         }
         X::flag(V.flags, bb, 4, bad & cx.valid & (cx.r == 0));
+    }
+
+    // =====================================================================================================================
+    // Backward pass of the quad fronts (k_m2_backward_quads): x_piv = U11^-1 (w_piv - U12 x_anc), parents before children.
+    // lane = 16 q + r: instance q, pivot row r (p <= 16: one row set).  The ancestors' unknowns come straight from w (their fronts
+    // stored them there: the launch before for cooperative / per-instance parents, earlier in this wavefront's walk otherwise); the
+    // panels' loads are requested before the fence that makes the parent's stores visible.  Same summation order as
+    // front_backward_lean + tri_upper on a 64-lane team (four interleaved partial sums of U12 x_anc, subtracted in order; the
+    // refined quotient of the triangular solve): the results are those of the per-instance path.
+    // =====================================================================================================================
+    template <class X>
+    PEQ_DEV void quad_backward_list(DevView const& V, int quad, int list)
+    {
+        using vd = typename X::vd;
+        using vi = typename X::vi;
+        using vu = typename X::vu;
+        using vm = typename X::vm;
+        int const* lp = V.q_lists + 2 * list;
+        int const nfr = lp[1];
+        if(nfr <= 0) return;
+        int first = 0;  // fronts of the lists before this one
+        for(int L = 0; L < list; ++L) first += V.q_lists[2 * L + 1];
+        int const* ql = V.q_list + static_cast<long long>(quad) * 4;
+        int const b0 = ql[0];
+        vi const lane = X::lane();
+        vi const q = lane >> 4, r = lane & 15;
+        vi const b = X::ld_i32(ql, X::to_u(q) << 2);
+        vm const valid = b >= 0;
+        vi const bb = X::sel(valid, b, vi(b0));
+        vu const d = X::to_u(bb - b0);
+        vu const offF = d * static_cast<unsigned>(V.factor_doubles * 8ll), offW = d * static_cast<unsigned>(V.rows * 8ll);
+        char const* baseF = reinterpret_cast<char const*>(V.factor + static_cast<long long>(b0) * V.factor_doubles);
+        char* baseW = reinterpret_cast<char*>(V.w + static_cast<long long>(b0) * V.rows);
+        int const* blk = V.q_bprog + static_cast<long long>(first) * 40;
+        for(int i = 0; i < nfr; ++i, blk += 40)
+        {
+            int const m = blk[0], p = blk[1], c0 = blk[2], u = blk[3];
+            unsigned const pf = static_cast<unsigned>(static_cast<long long>(static_cast<unsigned>(blk[4])) | (static_cast<long long>(blk[5]) << 32)) * 8u;
+            unsigned const mb = static_cast<unsigned>(m) * 8u, pb = static_cast<unsigned>(p) * 8u;
+            unsigned const pu = pf + static_cast<unsigned>(m) * pb;
+            vm const own = r < p;
+            vu const ro = X::to_u(X::sel(own, r, vi(0))) << 3;  // (lanes beyond the pivots re-read row 0 and drop it)
+            // U12 row r (p x u, ld p) and U11 column k, rows <= k (top block of the L panel, ld m): independent of w
+            vd u12[32], ucol[16];
+#pragma unroll
+            for(int J = 0; J < 32; J += 4)
+            {
+                if(J < u)
+                {
+#pragma unroll
+                    for(int j = J; j < J + 4; ++j) u12[j] = X::ld(baseF, offF + ro + (pu + static_cast<unsigned>(j < u ? j : 0) * pb));
+                }
+                else
+                {
+#pragma unroll
+                    for(int j = J; j < J + 4; ++j) u12[j] = vd(0.0);
+                }
+            }
+#pragma unroll
+            for(int K = 0; K < 16; K += 4)
+            {
+                if(K < p)
+                {
+#pragma unroll
+                    for(int k = K; k < K + 4; ++k) ucol[k] = X::ld(baseF, offF + ro + (pf + static_cast<unsigned>(k < p ? k : 0) * mb));
+                }
+                else
+                {
+#pragma unroll
+                    for(int k = K; k < K + 4; ++k) ucol[k] = vd(0.0);
+                }
+            }
+            X::fence();  // the unknowns of the parent (the front before in this walk, or an earlier launch) are in memory
+            vd const wi = X::ld(baseW, offW + static_cast<unsigned>(c0) * 8u + ro);
+            vd acc[4] = {vd(0.0), vd(0.0), vd(0.0), vd(0.0)};
+#pragma unroll
+            for(int J = 0; J < 32; J += 4)
+            {
+                if(J < u)
+                {
+#pragma unroll
+                    for(int j = J; j < J + 4; ++j)
+                    {
+                        // x_anc[j]: one value per instance (every lane of a quad reads the same address)
+                        vd const xa = X::ld(baseW, offW + static_cast<unsigned>(blk[8 + (j < u ? j : 0)]) * 8u);
+                        if(j < u) acc[j & 3] = acc[j & 3] + u12[j] * xa;
+                    }
+                }
+            }
+            vd ti = wi;
+#pragma unroll
+            for(int g = 0; g < 4; ++g) ti = ti - acc[g];
+            // U11 x = t: lane r owns x_r; the dependent chain runs on row broadcasts
+            vd dg = vd(1.0);
+#pragma unroll
+            for(int k = 0; k < 16; ++k) dg = X::sel(own & (r == k), ucol[k], dg);
+            vd const rr = vd(1.0) / dg;
+#pragma unroll
+            for(int k = 15; k >= 0; --k)
+            {
+                if(k < p)
+                {
+                    vd const uc = X::sel(r < k, ucol[k], vd(0.0));
+                    vd qv = ti * rr;
+                    vd const e = X::fma(-qv, dg, ti);
+                    qv = X::fma(e, rr, qv);
+                    vd const xk = X::bcast(qv, k);
+                    ti = X::sel(r == k, xk, ti);
+                    ti = X::sel(r < k, X::fma(-uc, xk, ti), ti);
+                }
+            }
+            X::when(valid & own, [&] { X::st(baseW, offW + static_cast<unsigned>(c0) * 8u + (X::to_u(r) << 3), ti); });
+        }
     }
 }  // namespace pe

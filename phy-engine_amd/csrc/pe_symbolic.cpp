@@ -1148,6 +1148,22 @@ namespace pe
                 for(int i = S.wave_ptr[part * (W + 1) + w]; i < S.wave_ptr[part * (W + 1) + w + 1]; ++i)
                     if(S.f_quad[S.wave_list[i]]) lists[static_cast<size_t>(part) * W + w].push_back(S.wave_list[i]);
         build_quad_program(S, lists, S.q_lds_doubles, S.q_prog, S.q_lists, S.q_lane);
+        S.q_bprog.clear();
+        for(auto const& lst: lists)  // (q_lists[2 L + 1] fronts of list L, stored back to back in list order: block index = fronts before it)
+            for(auto it = lst.rbegin(); it != lst.rend(); ++it)
+            {
+                int const s = *it;
+                size_t const h = S.q_bprog.size();
+                S.q_bprog.resize(h + Symbolic::Q_BACK, 0);
+                int* q = S.q_bprog.data() + h;
+                q[0] = S.f_p[s] + S.f_u[s];
+                q[1] = S.f_p[s];
+                q[2] = S.f_col0[s];
+                q[3] = S.f_u[s];
+                q[4] = static_cast<int>(S.f_lptr[s] & 0xffffffffll);
+                q[5] = static_cast<int>(S.f_lptr[s] >> 32);
+                for(int j = 0; j < S.f_u[s]; ++j) q[8 + j] = S.f_rows[S.f_rows_ptr[s] + j];
+            }
         // MID fronts: the subtrees of kind-3 fronts inside a part's cooperative list, dealt out to W lists per part (longest first)
         S.n_mid = 0;
         std::vector<std::vector<int>> mlists(static_cast<size_t>(K) * W);

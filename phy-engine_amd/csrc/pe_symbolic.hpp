@@ -134,6 +134,13 @@ namespace pe
         long long q_lds_kept{}, q_lds_total{};  // doubles of update matrices (+ vectors) of wave fronts kept in LDS / in all (statistics)
         std::vector<int> q_prog, q_lists;
         std::vector<unsigned char> q_lane;
+        // backward pass of the quad fronts (k_m2_backward_quads): per list the same fronts in REVERSE order (parents first), Q_BACK ints each:
+        //   [0] m  [1] p  [2] first pivot  [3] u  [4,5] f_lptr lo / hi  [8 .. 8 + u) permuted indices of the update rows (f_rows)
+        enum : int
+        {
+            Q_BACK = 40
+        };
+        std::vector<int> q_bprog;
         // the same for the MID fronts (f_kind 3; row sets 1..4): q2_lists[2 L] / [2 L + 1] for list L = part * n_waves + k
         std::vector<int> q2_prog, q2_lists;
         std::vector<unsigned char> q2_lane;

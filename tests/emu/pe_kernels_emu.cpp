@@ -38,6 +38,13 @@ namespace pe
                 for(int list = 0; list < V.n_parts * V.n_waves; ++list) quad_factor_mid_list<QuadEmu>(V, quad, list);
     }
 
+    static void emu_backward_quads(DevView const& V)
+    {
+        if(!V.quad_back) return;
+        for(int quad = 0; quad < V.n_quads; ++quad)
+            for(int list = 0; list < V.n_parts * V.n_waves; ++list) quad_backward_list<QuadEmu>(V, quad, list);
+    }
+
     struct SerialTeam
     {
         int nw;
@@ -257,6 +264,14 @@ namespace pe
             for(int l = V.n_top_levels - 1; l >= 0; --l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
+        }
+        emu_backward_quads(V);  // (its own launch on the device, behind the parts' backward pass)
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
             for(int k = 0; k < V.rows; ++k)
             {
                 int const r = V.col_src[k];
@@ -310,6 +325,16 @@ namespace pe
             for(int l = V.n_top_levels - 1; l >= 0; --l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
+        }
+        emu_backward_quads(V);
+        for(int b = 0; b < V.batch; ++b)
+        {
+            if(!V.active[b]) continue;
+            double* x = V.x + static_cast<long long>(b) * V.rows;
+            double const* xp = V.xprev + static_cast<long long>(b) * V.rows;
+            double* xs = V.xsave + static_cast<long long>(b) * V.rows;
+            double* w = V.w + static_cast<long long>(b) * V.rows;
+            double n4[4];
             for(int k = 0; k < V.rows; ++k) x[V.col_src[k]] = xs[V.col_src[k]] + w[k];
             V.flags[b] = 0;
             residual_norms(tm, V, b, nullptr, n4);

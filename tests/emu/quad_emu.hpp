@@ -34,6 +34,7 @@ namespace pe
         for(int l = 0; l < 64; ++l) r.v[l] = static_cast<T>(a.v[l] op static_cast<T>(b)); \
         return r;                                                           \
     }
+    PE_V64_BIN(/)
     PE_V64_BIN(+)
     PE_V64_BIN(-)
     PE_V64_BIN(*)
@@ -163,6 +164,7 @@ namespace pe
                 }
         }
         static void lds_fence() {}
+        static void fence() {}
         template <class T>
         static Vec64<T> sel(vm const& m, Vec64<T> const& a, Vec64<T> const& b)
         {
