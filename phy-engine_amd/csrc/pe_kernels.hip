@@ -921,6 +921,10 @@ namespace pe
         }
         static __device__ __forceinline__ vi ld_i32(int const* base, vu off) { return *reinterpret_cast<int const*>(reinterpret_cast<char const*>(base) + off); }
         static __device__ __forceinline__ void st(char* base, vu off, vd v) { *reinterpret_cast<double*>(base + off) = v; }
+        static __device__ __forceinline__ void st_if(bool all, vm mask, char* base, vu off, vd v)
+        {
+            if(all || mask) *reinterpret_cast<double*>(base + off) = v;
+        }
         template <class F>
         static __device__ __forceinline__ void when(vm mask, F&& body)  // one exec region for all the stores of `body`
         {

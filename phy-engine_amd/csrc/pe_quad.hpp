@@ -29,6 +29,7 @@
 //   X::bcast(v, k)         value of lane 16 (lane / 16) + k, k a compile-time constant after unrolling
 //   X::ld / ld_u32x4 / ld_i32 (uniform base, per-lane byte offset), X::st(base, offset, value) inside X::when(mask, body)
 //   X::lds_ld(byte address) / lds_st(byte address, value) inside X::when / lds_fence(): the wavefront's LDS (update-matrix stack)
+//   X::st_if(all, mask, base, offset, value): inside X::when -- store for every lane of the region if `all` (uniform), else where mask
 //   X::fence(): the wavefront's earlier global stores are visible to its later loads (other lanes included)
 //   X::sel(mask, a, b), X::rcp(d), X::fma(a, b, c), X::bad(piv), X::flag(ptr, index, bits, mask)
 #pragma once
@@ -298,7 +299,9 @@ namespace pe
 #pragma unroll
                         for(int C = 0; C < M; ++C)
                         {
-                            if(C < p) X::st(cx.baseF, fo + (pf + static_cast<unsigned>(C) * mb), a[0][C]);
+                            // (top block: without a separate forward pass nobody reads the multipliers below the diagonal of U11 --
+                            //  the backward passes take rows <= column only -- so they are not written: 15 % of this kernel's bytes)
+                            if(C < p) X::st_if(V.keep_l21 != 0 || C >= 15, r <= C, cx.baseF, fo + (pf + static_cast<unsigned>(C) * mb), a[0][C]);
                             else if(C < m)
                                 X::st(cx.baseF, fo + (pu + static_cast<unsigned>(C - p) * pb), a[0][C]);
                         }

@@ -165,6 +165,12 @@ namespace pe
         }
         static void lds_fence() {}
         static void fence() {}
+        static void st_if(bool all, vm const& mask, char* base, vu const& off, vd const& v)
+        {
+            vm const& m = cur();
+            for(int l = 0; l < 64; ++l)
+                if(m.v[l] && (all || mask.v[l])) std::memcpy(base + off.v[l], &v.v[l], 8);
+        }
         template <class T>
         static Vec64<T> sel(vm const& m, Vec64<T> const& a, Vec64<T> const& b)
         {
