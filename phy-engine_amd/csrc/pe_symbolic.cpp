@@ -884,15 +884,38 @@ namespace pe
                 S.wave_stack = std::max(S.wave_stack, S.f_wstack[s] + S.f_p[s] + S.f_u[s]);
                 if(!inner) wroots[part_of[s]].push_back(s);
             }
+            // With the lane-group kernel the quad fronts of a list cost the part's workgroup nothing (they were factored by the launch
+            // before, one wavefront per (quad, list), dynamically scheduled: the balance BETWEEN lists hardly matters there), so the W
+            // wavefronts of a part are balanced on what they really walk -- the non-quad fronts (measured before: 140..230 us per
+            // wavefront of a part with the lists balanced on all fronts) -- and the pure-quad subtrees even out the quad lists after that.
+            std::vector<double> sub_nq(nf, 0.0);
+            for(int s = 0; s < nf; ++s)
+            {
+                if(S.f_kind[s] != 0) continue;
+                if(!S.f_quad[s]) sub_nq[s] += cost[s];
+                int const P = S.f_parent[s];
+                if(P >= 0 && S.f_kind[P] == 0 && part_of[P] == part_of[s]) sub_nq[P] += sub_nq[s];
+            }
             for(int q = 0; q < K; ++q)
             {
                 auto& r = wroots[q];
-                std::sort(r.begin(), r.end(), [&](int a, int b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
-                std::vector<double> load(W, 0.0);
+                std::sort(r.begin(), r.end(),
+                          [&](int a, int b)
+                          {
+                              if(sub_nq[a] != sub_nq[b]) return sub_nq[a] > sub_nq[b];
+                              return sub[a] != sub[b] ? sub[a] > sub[b] : a < b;
+                          });
+                std::vector<double> load(W, 0.0), load_q(W, 0.0);
                 for(int root: r)
                 {
-                    int const w = static_cast<int>(std::min_element(load.begin(), load.end()) - load.begin());
-                    load[w] += sub[root];
+                    int w = 0;
+                    for(int k = 1; k < W; ++k)
+                    {
+                        bool const better = sub_nq[root] > 0.0 ? (load[k] < load[w] || (load[k] == load[w] && load_q[k] < load_q[w])) : load_q[k] < load_q[w];
+                        if(better) w = k;
+                    }
+                    load[w] += sub_nq[root];
+                    load_q[w] += sub[root] - sub_nq[root];
                     exec_of[root] = q * (W + 1) + w;
                 }
             }
