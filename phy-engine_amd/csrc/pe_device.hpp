@@ -109,7 +109,8 @@ namespace pe
         unsigned const* f_bmask;     // per child edge: 16-row blocks of the parent's update rows the child touches (bit min(t, 31))
         int const *f_asm_ptr, *asm_slot, *asm_pos;
         // destination-centric assembly lists (pe_symbolic.hpp: build_assembly_lists) and the LDS layout of every front
-        int const* f_mode;             // 0 whole front, 1 pivot panels, 2 chain link
+        int const* f_mode;             // 0 whole front, 1 pivot panels, 2 chain link, 3 chain link continued in LDS (top run, see f_keep)
+        int const* f_keep{};           // per front: 1 = its Schur block stays in the LDS image for its parent (a mode-3 front, next in the same top run)
         int const *gl_ptr, *gl_rptr;   // [nfronts + 1] into gl_dst / gl_cnt
         long long const* gl_sptr;      // [nfronts + 1] into gl_src
         unsigned short const* gl_dst;
@@ -123,6 +124,8 @@ namespace pe
         int const *wave_ptr, *wave_list, *coop_ptr, *coop_list, *top_ptr, *top_list;
         int n_parts, n_top_levels, n_waves;
         int top_cnt[64];        // fronts per top level (host-side copy for the launch geometry)
+        int top_wide[64]{};     // 1: the level runs one 16-wavefront workgroup per front with a CU's whole LDS (k_m2_factor_top_wide)
+        int lds_top_doubles{};  // dynamic LDS of those launches, in doubles (>= lds_doubles)
         int* active;            // [.] multi-workgroup mode: instances still iterating
         int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)

@@ -298,8 +298,20 @@ namespace
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
         // the LDS caps are fixed now: layout of every front + the assembly lists that go with it
-        if(!pe::build_assembly_lists(S, V.lds_slot, V.lds_doubles - 2)) return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
+        // top levels that leave most CUs without a workgroup run ONE 16-wavefront workgroup per front (k_m2_factor_top_wide): always in
+        // the one-workgroup-per-CU geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances
+        // <= CUs + 25 %).  Such a workgroup owns its CU's LDS: whole-front layout up to order ~141, chain links continued in LDS.
+        {
+            bool const wide_knob = env_int0("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;
+            bool const chain_lds = env_int0("PHY_ENGINE_HIP_TOP_CHAIN_LDS", 1) != 0;  // developer knob: 0 = round 2's layout of the top fronts
+            long long const whole_cu = h->lds_limit / 8 - 160 - 8;
+            for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * batch <= 320)) ? 1 : 0;
+            V.lds_top_doubles = chain_lds ? static_cast<int>(std::max<long long>(V.lds_doubles, whole_cu)) : V.lds_doubles;
+            if(!pe::build_assembly_lists(S, V.lds_slot, V.lds_doubles - 2, chain_lds ? V.top_wide : nullptr, V.lds_top_doubles - 2))
+                return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
+        }
         HIPCHK(h, pool.upload(V.f_mode, S.f_mode));
+        HIPCHK(h, pool.upload(V.f_keep, S.f_keep));
         HIPCHK(h, pool.upload(V.gl_ptr, S.gl_ptr));
         HIPCHK(h, pool.upload(V.gl_rptr, S.gl_rptr));
         HIPCHK(h, pool.upload(V.gl_sptr, S.gl_sptr));
@@ -539,6 +551,14 @@ namespace
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
         h->active_dev.clear();  // (the quad list behind the mask depends on this analysis' strides)
+        if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
+        {
+            auto const& S = h->sym;
+            std::fprintf(stderr, "[pe_hip]   top fronts, LDS layout (0 whole, 1 panels, 2 chain link, 3 chain link continued in LDS; * = 16-wavefront level, %d doubles):", h->V.lds_top_doubles);
+            for(std::size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
+                for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) std::fprintf(stderr, " %d%s", S.f_mode[S.top_list[k]], h->V.top_wide[l] ? "*" : "");
+            std::fprintf(stderr, "\n");
+        }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
             std::fprintf(stderr, "[pe_hip]   LDS plan (doubles): factor %d, solves %d, backward %d (wave slot %d = t %d + stage %d + 64 + stack %d), wave front slot %d\n", h->V.lds_doubles,
                          h->V.lds_solve_doubles, h->V.lds_solve_b_doubles, h->V.lds_sslot, h->V.wave_m, h->V.lds_wave_stage, h->V.lds_sslot - h->V.lds_bstack_off, h->V.lds_slot);

@@ -539,8 +539,20 @@ namespace pe
     //   (b)  the trailing panels are updated by 16x16x4 fp64 MFMA tiles (tm.tile_*: v_mfma_f64_16x16x4_f64),
     // then the Schur block S = (children's contributions) - L21 * U12 is produced by MFMA tiles (K = p) that
     // PULL the children's contributions through the inverse maps f_inv and write S exactly once.
-    template <class Team>
-    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, int profile, bool fuse)
+    // A run of single-front top levels handled by one workgroup (k_m2_factor_top_wide): a front whose Schur block STAYS in its LDS
+    // image (V.f_keep) hands the image over to its parent, a chain link in mode 3 -- the link's front is that block, where it lies.
+    struct ChainState
+    {
+        double* img{};  // the block (column major, leading dimension ld) ...
+        int ld{};
+        double* g{};    // ... and the update part of the right-hand-side column that belongs to it
+    };
+
+    // CHAIN (compile time): only the run kernel of the wide top levels carries the hand-over -- every other instantiation compiles to
+    // the code it was before (the extra paths cost the 128-VGPR kernels registers: 17 spilled VGPRs in k_m2_factor_parts<4> when
+    // they were decided at run time).
+    template <class Team, bool CHAIN = false>
+    PE_DEV bool front_factor(Team const& tm, DevView const& V, int b, int s_in, double* lds, int cap, int profile, bool fuse, ChainState* cs = nullptr)
     {
         int const s = tm.uniform(s_in);
         int const p = V.f_p[s], u = V.f_u[s], m = p + u;
@@ -557,17 +569,25 @@ namespace pe
         // block loop g[0..p) is the forward-substituted solution of these pivots and g[p..m) this front's update vector.
         // Saves the separate forward pass over the factor panels whenever a factorisation is followed by a solve.
         int const mode = tm.uniform(V.f_mode[s]);  // fixed with the launch geometry (build_assembly_lists): same rule, one place
-        bool const full = mode == 0;
+        // mode 3: a chain link whose front already sits in LDS -- the Schur block its child (the front before it in this run of top
+        // levels, whole-front layout) left in place: no zeroing, no assembly of the child, no trip of that block through the arena.
+        // Same values in the same cells, same block loop: bit-identical to the link assembled from the arena.
+        bool const cont = CHAIN && mode == 3;
+#if !defined(__HIPCC__)
+        assert((!cont || (cs && cs->img)) && "a mode-3 front needs the image its child left in LDS");
+#endif
+        bool const full = mode == 0 || cont;
         bool const chain = mode == 2;  // the single child's update matrix IS this front: f_rel of the child is the identity
-        int const ldl = pe_ld(m);               // LDS leading dimension of the L panel / of the whole image (odd: bank spread)
+        bool const keep = CHAIN && cs && V.f_keep[s];  // this front's Schur block stays in the image for its parent (mode 3)
+        int const ldl = cont ? cs->ld : pe_ld(m);  // LDS leading dimension of the L panel / of the whole image (odd: bank spread)
         int const ldu = full ? ldl : pe_ld(p);  // ... of the U panel
         int const nlds = full ? ldl * m : ldl * p + ldu * u;
 #if !defined(__HIPCC__)
-        assert(nlds + (fuse ? m : 0) <= cap && "front image + right-hand-side column overrun the team's LDS region");
+        assert((cont || nlds + (fuse ? m : 0) <= cap) && "front image + right-hand-side column overrun the team's LDS region");
 #endif
-        double* Lp = lds;
-        double* Up = lds + ldl * p;
-        double* g = lds + nlds;  // [m] right-hand-side column (fuse)
+        double* Lp = cont ? cs->img : lds;
+        double* Up = Lp + ldl * p;
+        double* g = cont ? cs->g : lds + nlds;  // [m] right-hand-side column (fuse)
         int const T = tm.size(), t0 = tm.tid();
         int const c0 = V.f_col0[s];
         double* w = V.w + static_cast<long long>(b) * V.rows;
@@ -580,13 +600,24 @@ namespace pe
         double const v0 = e0 < e1 ? a[V.asm_slot ? V.asm_slot[e0] : e0] : 0.0;
         double const w0 = (fuse && t0 < p) ? w[c0 + t0] : 0.0;
         PE_MARK("zero");
-        for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
-        if(fuse)
+        if(cont)
         {
-            if(t0 < m) g[t0] = w0;
-            for(int i = t0 + T; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
+            // g[0..m) holds the child's update vector: the pivot part takes this front's slice of the right-hand side on top
+            // (w + vc in the arena path, vc + w here: the same sum)
+            if(fuse && t0 < p) g[t0] += w0;
+            if(fuse)
+                for(int i = t0 + T; i < p; i += T) g[i] += w[c0 + i];
         }
-        tm.sync_lds();
+        else
+        {
+            for(int i = t0; i < nlds; i += T) lds[i] = 0.0;
+            if(fuse)
+            {
+                if(t0 < m) g[t0] = w0;
+                for(int i = t0 + T; i < m; i += T) g[i] = i < p ? w[c0 + i] : 0.0;
+            }
+            tm.sync_lds();
+        }
         PE_MARK("place");
         auto place = [&](int pos, double v)
         {
@@ -600,10 +631,11 @@ namespace pe
         long long const cka = tm.clock();
         PE_MARK("children");
         // full fence: the children's update matrices (global memory, written by other lanes / wavefronts) become visible
-        if(ch1 > ch0) tm.sync();
+        if(ch1 > ch0 && !cont) tm.sync();
         else
             tm.sync_lds();
-        if(chain)
+        if(cont) {}
+        else if(chain)
         {
             // the child's update matrix IS this front (a long separator split into links): straight copies
             int const c = V.f_child[ch0];
@@ -947,7 +979,11 @@ namespace pe
                             }
                         }
                         tm.tile_mulsub(acc, Lp + p + i0, ldl, Up + j0 * ldu, ldu, mr, nc, p, lane);
-                        tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
+                        // (keep: the block stays where it is -- the parent, a mode-3 chain link, works on it in place; a tile is read
+                        //  and written by the same wavefront, once)
+                        if(keep) tm.tile_store(acc, Up + p + i0 + j0 * ldu, ldu, mr, nc, lane);
+                        else
+                            tm.tile_store(acc, Ss + i0 + j0 * u, u, mr, nc, lane);
                     }
                 });
         }
@@ -957,7 +993,14 @@ namespace pe
         {
             for(int i = t0; i < p; i += T) w[c0 + i] = g[i];
             double* vs = arena + V.f_sptr[s] + static_cast<long long>(u) * u;
-            for(int i = t0; i < u; i += T) vs[i] = g[p + i];
+            if(!keep)
+                for(int i = t0; i < u; i += T) vs[i] = g[p + i];
+        }
+        if(CHAIN && cs)
+        {
+            cs->img = keep ? Up + p : nullptr;
+            cs->ld = ldl;
+            cs->g = g + p;
         }
         double* Lg = fac + V.f_lptr[s];
         // What later phases read: the backward pass needs U11 (upper triangle of the top p x p block of the L panel) and U12;

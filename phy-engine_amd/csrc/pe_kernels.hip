@@ -697,10 +697,13 @@ namespace pe
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         HipTeam tm;
+        // (this workgroup owns its CU's LDS: whole-front layout up to V.lds_top_doubles, and inside a run of single-front levels a
+        //  chain link finds its front where the front before it left the Schur block -- ChainState, pe_front.hpp)
+        ChainState cs;
         for(int l = level; l < level + nlev; ++l)
         {
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            if(!front_factor<HipTeam, true>(tm, V, b, s, pe_lds, V.lds_top_doubles - 2, 0, true, &cs))
             {
                 if(tm.tid() == 0) atomicOr(V.flags + b, 4);
                 return;
@@ -1088,7 +1091,7 @@ namespace pe
         {
             hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top<MINW>), lds);
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_wide), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_wide), static_cast<size_t>(V.lds_top_doubles) * sizeof(double));
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_mid), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts<MINW>), lds_s);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_s);
@@ -1137,15 +1140,14 @@ namespace pe
             }
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
-            static bool const wide_knob = getenv_int("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;
             for(int l = 0; l < V.n_top_levels; l += run(l))
             {
                 // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
                 // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %)
-                bool const wide = wide_knob && (MINW == 2 || V.top_cnt[l] * B <= 320);
+                bool const wide = V.top_wide[l] != 0;  // (the rule lives in upload_symbolic: the fronts' LDS layout depends on it)
                 static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
                 bool const mid = !wide && MINW == 4 && T == 256 && V.top_cnt[l] * B <= mid_knob;
-                if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), lds, st, V, l, run(l));
+                if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), static_cast<size_t>(V.lds_top_doubles) * sizeof(double), st, V, l, run(l));
                 else if(mid)
                     hipLaunchKernelGGL(k_m2_factor_top_mid, dim3(V.top_cnt[l], B), dim3(512), lds, st, V, l, run(l));
                 else

@@ -1223,10 +1223,20 @@ namespace pe
         build_quad_program(S, mlists, 0, S.q2_prog, S.q2_lists, S.q2_lane);
     }
 
-    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team)
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide, long long cap_top)
     {
         int const nf = S.nfronts;
         S.f_mode.assign(nf, 0);
+        S.f_keep.assign(nf, 0);
+        // top fronts of a level that runs one wide workgroup per front own a CU's LDS: larger cap, and a chain link that follows its
+        // child in the same run of single-front levels (same workgroup, one after the other) finds its front already in LDS
+        std::vector<int> wide_level(nf, -1);  // level of a top front at a wide level, else -1
+        if(top_wide && cap_top > 0)
+            for(size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
+                // (single-front levels only: measured at 128 instances, the levels with two fronts run 3..5 us SLOWER in the whole-front
+                //  layout of the larger cap -- 27 -> 30, 31 -> 36 us -- while the run of single-front levels gains 12 us, 178 -> 166)
+                if(top_wide[l] && S.top_ptr[l + 1] - S.top_ptr[l] == 1)
+                    for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) wide_level[S.top_list[k]] = static_cast<int>(l);
         S.gl_ptr.assign(nf + 1, 0);
         S.gl_rptr.assign(nf + 1, 0);
         S.gl_sptr.assign(nf + 1, 0);
@@ -1243,13 +1253,26 @@ namespace pe
         for(int s = 0; s < nf; ++s)
         {
             long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
-            long long const cap = S.f_kind[s] == 0 ? cap_wave : cap_team;
+            long long const cap = S.f_kind[s] == 0 ? cap_wave : (wide_level[s] >= 0 ? std::max(cap_team, cap_top) : cap_team);
             int const ch0 = S.f_child_ptr[s], ch1 = S.f_child_ptr[s + 1];
             long long const ldl = pe_ld(static_cast<int>(m)), ldp = pe_ld(static_cast<int>(p));  // odd LDS leading dimensions (pe_device.hpp)
             bool const full = ldl * m + m <= cap;
-            bool const chain = !full && ch1 - ch0 == 1 && S.f_u[S.f_child[ch0]] == m;
+            bool const link = ch1 - ch0 == 1 && S.f_u[S.f_child[ch0]] == m;
+            bool const chain = !full && link;
             S.f_mode[s] = full ? 0 : (chain ? 2 : 1);
-            if(!chain && ch1 > ch0)
+            if(link && wide_level[s] >= 1)
+            {
+                // continued in LDS: the child is the only front of the level below, ran in the whole-front layout (its Schur block sits
+                // in its image) in the same workgroup right before this front
+                int const c = S.f_child[ch0], l = wide_level[s];
+                bool const same_run = wide_level[c] == l - 1 && S.top_ptr[l + 1] - S.top_ptr[l] == 1 && S.top_ptr[l] - S.top_ptr[l - 1] == 1;
+                if(same_run && (S.f_mode[c] == 0 || S.f_mode[c] == 3))
+                {
+                    S.f_mode[s] = 3;
+                    S.f_keep[c] = 1;
+                }
+            }
+            if(S.f_mode[s] != 3 && !chain && ch1 > ch0)
             {
                 long long const nlds = full ? ldl * m : ldl * p + ldp * u;
                 if(nlds + m > 65535)

@@ -102,7 +102,9 @@ namespace pe
         //   n_r = gl_cnt[gl_rptr[s] + r]               cells with more than r sources (cells are sorted by source count, descending,
         //                                              then by the address of the first source: coalesced loads of the first child).
         // One sweep without barriers assembles all children; the summation order of a cell is the children's order.
-        std::vector<int> f_mode;                // 0 whole front in LDS, 1 pivot panels in LDS + pulled Schur tiles, 2 chain link
+        std::vector<int> f_mode;                // 0 whole front in LDS, 1 pivot panels in LDS + pulled Schur tiles, 2 chain link,
+                                                // 3 chain link whose front is already in LDS: the Schur block its child left there (f_keep)
+        std::vector<int> f_keep;                // per front: 1 = the parent is a mode-3 front (the Schur block is not written to the arena)
         std::vector<int> gl_ptr, gl_rptr;       // [nfronts + 1]
         std::vector<long long> gl_sptr;         // [nfronts + 1]
         std::vector<unsigned short> gl_dst;
@@ -162,5 +164,6 @@ namespace pe
 
     // cap_wave / cap_team: LDS doubles of a wavefront's slot / of the whole workgroup (the `cap` front_factor is called with).
     // Returns false (S.error set) when an offset does not fit its index type.
-    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team);
+    // `top_wide` (may be null): per top LEVEL, 1 = one workgroup per front with `cap_top` doubles of LDS (the 16-wavefront launch)
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide = nullptr, long long cap_top = 0);
 }  // namespace pe

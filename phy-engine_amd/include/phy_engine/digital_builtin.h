@@ -165,6 +165,31 @@ namespace phy_engine::model
     }
 
     // ------------------------------------------------------------------ gates
+    // every gate carries the same four attributes (e.g. digital/logical/and.h:38-130): 0 Ll, 1 Hl, 2 Tsu, 3 Th
+    namespace details
+    {
+        template <typename G>
+        inline bool set_gate_attribute(G& g, ::std::size_t n, variant vi) noexcept
+        {
+            if(n >= 4 || vi.type != variant_type::d) return false;
+            (n == 0 ? g.Ll : n == 1 ? g.Hl : n == 2 ? g.Tsu : g.Th) = vi.d;
+            return true;
+        }
+        template <typename G>
+        inline variant get_gate_attribute(G const& g, ::std::size_t n) noexcept
+        {
+            variant r{};
+            if(n >= 4) return r;
+            r.d = n == 0 ? g.Ll : n == 1 ? g.Hl : n == 2 ? g.Tsu : g.Th;
+            r.type = variant_type::d;
+            return r;
+        }
+        inline ::fast_io::u8string_view gate_attribute_name(::std::size_t n) noexcept
+        {
+            constexpr ::fast_io::u8string_view names[4] = {u8"Ll", u8"Hl", u8"Tsu", u8"Th"};
+            return n < 4 ? names[n] : ::fast_io::u8string_view{};
+        }
+    }  // namespace details
     struct NOT
     {
         inline static constexpr ::fast_io::u8string_view model_name{u8"NOT"};
@@ -177,6 +202,9 @@ namespace phy_engine::model
         digital_node_statement_t last_outputA{digital_node_statement_t::X};
     };
     inline pin_view generate_pin_view_define(model_reserve_type_t<NOT>, NOT& g) noexcept { return {g.pins, 2}; }
+    inline bool set_attribute_define(model_reserve_type_t<NOT>, NOT& g, ::std::size_t n, variant vi) noexcept { return details::set_gate_attribute(g, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<NOT>, NOT const& g, ::std::size_t n) noexcept { return details::get_gate_attribute(g, n); }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<NOT>, ::std::size_t n) noexcept { return details::gate_attribute_name(n); }
     inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<NOT>, NOT& g,
                                                                                        ::phy_engine::digital::digital_node_update_table& table, double now,
                                                                                        digital_update_method_t) noexcept
@@ -211,6 +239,12 @@ namespace phy_engine::model
     using NIMP = gate2<7>;
     template <int OP>
     inline pin_view generate_pin_view_define(model_reserve_type_t<gate2<OP>>, gate2<OP>& g) noexcept { return {g.pins, 3}; }
+    template <int OP>
+    inline bool set_attribute_define(model_reserve_type_t<gate2<OP>>, gate2<OP>& g, ::std::size_t n, variant vi) noexcept { return details::set_gate_attribute(g, n, vi); }
+    template <int OP>
+    inline variant get_attribute_define(model_reserve_type_t<gate2<OP>>, gate2<OP> const& g, ::std::size_t n) noexcept { return details::get_gate_attribute(g, n); }
+    template <int OP>
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<gate2<OP>>, ::std::size_t n) noexcept { return details::gate_attribute_name(n); }
     template <int OP>
     inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<gate2<OP>>, gate2<OP>& g,
                                                                                        ::phy_engine::digital::digital_node_update_table& table, double now,
@@ -254,6 +288,9 @@ namespace phy_engine::model
         digital_node_statement_t last_outputA{digital_node_statement_t::X};
     };
     inline pin_view generate_pin_view_define(model_reserve_type_t<YES>, YES& g) noexcept { return {g.pins, 2}; }
+    inline bool set_attribute_define(model_reserve_type_t<YES>, YES& g, ::std::size_t n, variant vi) noexcept { return details::set_gate_attribute(g, n, vi); }
+    inline variant get_attribute_define(model_reserve_type_t<YES>, YES const& g, ::std::size_t n) noexcept { return details::get_gate_attribute(g, n); }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<YES>, ::std::size_t n) noexcept { return details::gate_attribute_name(n); }
     inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<YES>, YES& g,
                                                                                        ::phy_engine::digital::digital_node_update_table& table, double now,
                                                                                        digital_update_method_t) noexcept
@@ -302,7 +339,7 @@ namespace phy_engine::model
         inline static constexpr ::fast_io::u8string_view identification_name{u8"INPUT"};
         pin pins{{u8"o"}};
         double Ll{0.0}, Hl{5.0};
-        digital_node_statement_t outputA{digital_node_statement_t::X};
+        digital_node_statement_t outputA{};  // (input.h:24: value-initialised = L)
         digital_node_statement_t last_outputA{digital_node_statement_t::X};
     };
     inline pin_view generate_pin_view_define(model_reserve_type_t<INPUT>, INPUT& g) noexcept { return {&g.pins, 1}; }
@@ -320,7 +357,7 @@ namespace phy_engine::model
         r.type = variant_type::digital;
         return r;
     }
-    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<INPUT>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"value"} : ::fast_io::u8string_view{}; }
+    inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<INPUT>, ::std::size_t n) noexcept { return n == 0 ? ::fast_io::u8string_view{u8"boolean"} : ::fast_io::u8string_view{}; }
     inline ::phy_engine::digital::need_operate_analog_node_t update_digital_clk_define(model_reserve_type_t<INPUT>, INPUT& g,
                                                                                        ::phy_engine::digital::digital_node_update_table& table, double,
                                                                                        digital_update_method_t) noexcept

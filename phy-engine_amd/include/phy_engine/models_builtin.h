@@ -148,14 +148,23 @@ namespace phy_engine::model
         pin pins[2]{{{u8"+"}}, {{u8"-"}}};
         branch branches{};
     };
+    // (VAC.h:28-84: the attributes are the amplitude, the frequency in Hz and the phase in degrees; the members hold rad/s and rad)
     inline bool set_attribute_define(model_reserve_type_t<VAC>, VAC& m, ::std::size_t n, variant vi) noexcept
     {
-        double VAC::* const f[3] = {&VAC::m_Vp, &VAC::m_omega, &VAC::m_phase};
-        return n < 3 && details::set_d(f[n], m, vi);
+        if(n >= 3 || vi.type != variant_type::d) return false;
+        if(n == 0) m.m_Vp = vi.d;
+        else if(n == 1)
+            m.m_omega = vi.d * (2.0 * 3.141592653589793238462643383279502884);
+        else
+            m.m_phase = vi.d * (3.141592653589793238462643383279502884 / 180.0);
+        return true;
     }
     inline variant get_attribute_define(model_reserve_type_t<VAC>, VAC const& m, ::std::size_t n) noexcept
     {
-        return n == 0 ? details::dvar(m.m_Vp) : n == 1 ? details::dvar(m.m_omega) : n == 2 ? details::dvar(m.m_phase) : variant{};
+        return n == 0   ? details::dvar(m.m_Vp)
+               : n == 1 ? details::dvar(m.m_omega / (2.0 * 3.141592653589793238462643383279502884))
+               : n == 2 ? details::dvar(m.m_phase / (3.141592653589793238462643383279502884 / 180.0))
+                        : variant{};
     }
     inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<VAC>, ::std::size_t n) noexcept
     {
@@ -177,7 +186,7 @@ namespace phy_engine::model
         inline static constexpr ::fast_io::u8string_view model_name{u8"IDC"};
         inline static constexpr model_device_type device_type{model_device_type::linear};
         inline static constexpr ::fast_io::u8string_view identification_name{u8"IDC"};
-        double I{1.0};
+        double I{0.2};  // (IDC.h:16)
         pin pins[2]{{{u8"+"}}, {{u8"-"}}};
     };
     inline bool set_attribute_define(model_reserve_type_t<IDC>, IDC& m, ::std::size_t n, variant vi) noexcept { return n == 0 && details::set_d(&IDC::I, m, vi); }
@@ -487,7 +496,7 @@ namespace phy_engine::model
         inline static constexpr ::fast_io::u8string_view model_name{u8"CCCS"};
         inline static constexpr model_device_type device_type{model_device_type::linear};
         inline static constexpr ::fast_io::u8string_view identification_name{u8"CCCS"};
-        double m_alpha{1.0};
+        double m_alpha{10.0};  // (CCCS.h:14)
         pin pins[4]{{{u8"S"}}, {{u8"T"}}, {{u8"P"}}, {{u8"Q"}}};
         branch branches{};
     };
@@ -625,7 +634,7 @@ namespace phy_engine::model
     }
     inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<single_pole_switch>, ::std::size_t n) noexcept
     {
-        return n == 0 ? ::fast_io::u8string_view{u8"cut_through"} : ::fast_io::u8string_view{};
+        return n == 0 ? ::fast_io::u8string_view{u8"Cut Through"} : ::fast_io::u8string_view{};
     }
     inline pin_view generate_pin_view_define(model_reserve_type_t<single_pole_switch>, single_pole_switch& m) noexcept { return {m.pins, 2}; }
     inline branch_view generate_branch_view_define(model_reserve_type_t<single_pole_switch>, single_pole_switch& m) noexcept { return {&m.branches, 1}; }
@@ -889,12 +898,12 @@ namespace phy_engine::model
     }
     inline variant get_attribute_define(model_reserve_type_t<relay>, relay const& m, ::std::size_t n) noexcept
     {
-        return n == 0 ? details::dvar(m.Von) : n == 1 ? details::dvar(m.Voff) : variant{};
+        return n == 0 ? details::dvar(m.Von) : n == 1 ? details::dvar(m.Voff) : n == 2 ? details::bvar(m.engaged) : variant{};  // (relay.h:51-53: 2 is read only)
     }
     inline ::fast_io::u8string_view get_attribute_name_define(model_reserve_type_t<relay>, ::std::size_t n) noexcept
     {
-        constexpr ::fast_io::u8string_view names[2] = {u8"Von", u8"Voff"};
-        return n < 2 ? names[n] : ::fast_io::u8string_view{};
+        constexpr ::fast_io::u8string_view names[3] = {u8"Von", u8"Voff", u8"Engaged"};
+        return n < 3 ? names[n] : ::fast_io::u8string_view{};
     }
     inline pin_view generate_pin_view_define(model_reserve_type_t<relay>, relay& m) noexcept { return {m.pins, 4}; }
     inline branch_view generate_branch_view_define(model_reserve_type_t<relay>, relay& m) noexcept { return {&m.branches, 1}; }

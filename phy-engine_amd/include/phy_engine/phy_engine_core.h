@@ -72,8 +72,9 @@ namespace phy_engine
             double t_stop{};
             double t_step{};
         };
-        struct DC
+        struct DC  // circuits/analyzer/DC.h:5-8
         {
+            double m_currentOmega{};
         };
         struct AC  // circuits/analyzer/AC.h
         {
@@ -1419,6 +1420,7 @@ namespace phy_engine
                         if(method & static_cast<unsigned>(digital_update_method_t::before_all_clk)) before_all_clk_digital_model.push_back(c);
                         else if(method & static_cast<unsigned>(digital_update_method_t::after_all_clk))
                             after_all_clk_digital_model.push_back(c);
+                        c->has_init = true;  // (circuit.h:585-590; the digital blocks have no init hook)
                         continue;  // event logic stays on the host
                     }
                     // circuit.h:595-635 (every analysis branch): global TNOM reaches a model that exposes "tnom" and still has the
@@ -1444,6 +1446,9 @@ namespace phy_engine
                         return false;
                     }
                     gpu_table_rows rows{};
+                    // (circuit.h:585-590: every model is initialised once; the models with a device table have no init hook -- the flag
+                    //  is kept because it is part of the wrapper data a PE-NL container carries, host-stamped models: prepare_overlay)
+                    if(c->ptr->has_gpu_table()) c->has_init = true;
                     if(!c->ptr->has_gpu_table() || !c->ptr->gpu_table(rows))
                     {
                         // no device table: a plug-in model with the reference's host hooks only -> host-stamp overlay

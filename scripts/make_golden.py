@@ -173,9 +173,41 @@ def sweep_statistics(name="mesh100_nl_stats32", W=100, seeds=range(1, 33), steps
 PROGRAMS = {"adc": ("ref_adc", "adc_c4.json"), "digital": ("ref_digital", "digital_blocks.json")}
 
 
+def penl_fixtures():
+    """tests/golden/penl/: PE-NL containers WRITTEN BY THE REAL REFERENCE (oracle/_ref/ref_penl = tests/cpp/penl_tool.cpp compiled against
+    the reference's pe_nl_fileformat.h and its vendored LevelDB) + the canonical dump the reference prints for each.  ref_reopened/ is a
+    database directory the reference's LevelDB has opened a second time: its recovery turned the write-ahead log into a sorted table."""
+    import shutil
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_penl")
+    out = os.path.join(GOLD, "penl")
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    def run(*a):
+        return subprocess.run([exe, *a], capture_output=True, text=True, check=True, cwd=out).stdout
+    open(os.path.join(out, "ref_full.dump"), "w").write(run("save", "ref_full.penl", "full", "file", "solve"))
+    open(os.path.join(out, "ref_struct.dump"), "w").write(run("dump", "ref_struct.penl") if run("save", "ref_struct.penl", "structure", "file") else "")
+    run("save", "ref_ck.penl", "runtime", "file", "solve")
+    open(os.path.join(out, "ref_zoo.dump"), "w").write(run("dump", "ref_zoo.penl") if run("save", "ref_zoo.penl", "structure", "file", "zoo") else "")
+    run("save", "ref_dir", "full", "dir", "solve")
+    run("save", "ref_reopened", "structure", "dir", "zoo")
+    run("dump", "ref_reopened")  # second open: LevelDB recovery writes 00000N.ldb and a new MANIFEST
+    for d in ("ref_dir", "ref_reopened"):
+        for junk in ("LOG", "LOG.old", "LOCK"):
+            p = os.path.join(out, d, junk)
+            if os.path.exists(p):
+                os.remove(p)
+    open(os.path.join(out, "schema.txt"), "w").write(subprocess.run([exe, "schema"], capture_output=True, text=True, check=True).stdout)
+    return sorted(os.listdir(out))
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(CASES)
     os.makedirs(GOLD, exist_ok=True)
+    if "penl" in names:
+        print(penl_fixtures(), flush=True)
+        names = [n for n in names if n != "penl"]
+        if not names:
+            sys.exit(0)
     for n in [n for n in names if n in PROGRAMS]:
         exe, fn = PROGRAMS[n]
         out = subprocess.run([os.path.join(ROOT, "oracle", "_ref", exe)], capture_output=True, text=True, check=True).stdout

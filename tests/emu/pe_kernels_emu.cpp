@@ -1,6 +1,7 @@
 // tests/emu/pe_kernels_emu.cpp -- TEST INFRASTRUCTURE ONLY: runs the team-generic code of pe_front.hpp on the host
 // with a one-thread team per instance and one-lane "wavefronts" executed one after the other (see
 // hip_shim/hip/hip_runtime_api.h).  Checks indexing and the orchestration; says nothing about races or performance.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -203,13 +204,13 @@ namespace pe
 
     hipError_t launch_tr_steps(hipStream_t, DevView const& V, double dt, int nsteps, bool reuse)
     {
-        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         for(int b = 0; b < V.batch; ++b) tr_steps(SerialTeam{V.n_waves}, V, b, dt, nsteps, reuse, mem.data());
         return hipSuccess;
     }
     hipError_t launch_dc_point(hipStream_t, DevView const& V, int mode)
     {
-        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         for(int b = 0; b < V.batch; ++b) dc_point(SerialTeam{V.n_waves}, V, b, mode, mem.data());
         return hipSuccess;
     }
@@ -221,7 +222,7 @@ namespace pe
     }
     hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, bool stamp_dynamic)
     {
-        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         SerialTeam tm{V.n_waves};
         for(int b = 0; b < V.batch; ++b)
         {
@@ -251,9 +252,11 @@ namespace pe
             {
                 for(int q = 0; q < V.n_parts; ++q)
                     if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
+                ChainState cs;  // (a run of single-front wide levels is ONE workgroup on the device: k_m2_factor_top_wide)
                 for(int l = 0; l < V.n_top_levels; ++l)
                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, 0, true)) V.flags[b] |= 4;
+                        if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles) - 2, 0, true, V.top_wide[l] ? &cs : nullptr))
+                            V.flags[b] |= 4;
             }
             else
             {
@@ -293,7 +296,7 @@ namespace pe
     }
     hipError_t launch_m2_refine(hipStream_t, DevView const& V)
     {
-        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         SerialTeam tm{V.n_waves};
         for(int b = 0; b < V.batch; ++b)
         {
@@ -319,9 +322,11 @@ namespace pe
             double n4[4];
             for(int q = 0; q < V.n_parts; ++q)
                 if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
+            ChainState cs;
             for(int l = 0; l < V.n_top_levels; ++l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                    if(!front_factor(tm, V, b, V.top_list[i], mem.data(), V.lds_doubles - 2, 0, true)) V.flags[b] |= 4;
+                    if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles) - 2, 0, true, V.top_wide[l] ? &cs : nullptr))
+                        V.flags[b] |= 4;
             for(int l = V.n_top_levels - 1; l >= 0; --l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
@@ -411,7 +416,7 @@ namespace pe
     }
     hipError_t launch_factor_solve(hipStream_t, DevView const& V, bool do_factor)
     {
-        std::vector<double> mem(static_cast<size_t>(V.lds_doubles) + 1);
+        std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         SerialTeam tm{V.n_waves};
         for(int b = 0; b < V.batch; ++b)
         {
