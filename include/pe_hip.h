@@ -182,7 +182,8 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
  * A user model that only has those hooks is evaluated ON THE HOST, once per Newton iteration, into a fixed set of matrix
  * cells / right-hand-side rows discovered once (what mna_keep_pattern_ready does, circuit.h:993-1003); the values are uploaded
  * and ADDED to the device-side stamp.  The hooks read node voltages, so the Newton loop of such a circuit is driven from the
- * host (one callback + one small upload per iteration); batch must be 1.
+ * host (one callback + one small upload per iteration and instance).  In a batch every group of calls is preceded by
+ * PE_HIP_OVERLAY_INSTANCE with the instance index in `mode` (see below); small-signal AC with an overlay needs batch = 1.
  *   rows / cols / rhs_rows  absolute MNA indices, 0-based: nodes 0 .. n_nodes-1, then branches (mna.h:60-157 G/B/C/D/I/E layout)
  *   representative          |value| per cell for the static pivot matching (the discovery stamp), may be NULL
  *   nonlinear               1: the circuit needs Newton iterations even without a built-in non-linear device
@@ -203,6 +204,10 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
  *                             omega, x the operating point; a_values holds 2 n_cells doubles -- the real parts of the cells, then the
  *                             imaginary parts -- and b_values 2 n_rhs likewise */
 #define PE_HIP_OVERLAY_AC 3
+/*     PE_HIP_OVERLAY_INSTANCE  batch > 1 only, before each of the calls above: they concern instance `mode` of the batch (x, a_values,
+ *                             b_values NULL).  Models with state of their own (a junction's last voltage, a companion history) keep one
+ *                             copy per instance and switch here; a callback that cannot returns non-zero and the analysis fails. */
+#define PE_HIP_OVERLAY_INSTANCE 4
 typedef int (*pe_hip_overlay_fn)(void* user, int event, int mode, double t, double dt, const double* x, double* a_values, double* b_values);
 int pe_hip_set_overlay(pe_hip_engine* h, int n_cells, const int* rows, const int* cols, const double* representative, int n_rhs, const int* rhs_rows,
                        int nonlinear, pe_hip_overlay_fn fn, void* user);

@@ -449,11 +449,6 @@ namespace pe
         hc.dv_drv = o; o += n_drives;
         if(overlay)
         {
-            if(batch != 1 && !overlay->empty())
-            {
-                hc.error = "a host-stamp overlay needs batch = 1";
-                return false;
-            }
             for(size_t i = 0; i < overlay->rows.size(); ++i)
                 if(overlay->rows[i] < 0 || overlay->rows[i] >= hc.rows || overlay->cols[i] < 0 || overlay->cols[i] >= hc.rows)
                 {

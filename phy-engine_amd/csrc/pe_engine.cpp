@@ -181,13 +181,17 @@ namespace
         return h->V.n_parts > 1 || h->hc.rows >= 3000;
     }
 
-    // host-stamp overlay: one callback (+ the upload of its values for ITERATE) on instance 0's current x
-    int overlay_call(pe_hip_engine* h, int event, int mode, double t, double dt)
+    // host-stamp overlay: one callback (+ the upload of its values for ITERATE) on the current x of instance b.  In a batch the
+    // callback is told first which instance the calls that follow concern (PE_HIP_OVERLAY_INSTANCE): models with state of their own
+    // (a junction's last voltage, a companion history) keep one copy per instance.
+    int overlay_call(pe_hip_engine* h, int event, int mode, double t, double dt, int b = 0)
     {
         auto const& hc = h->hc;
         h->ov_x.resize(static_cast<size_t>(hc.rows));
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        if(hc.rows) HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
+        if(hc.batch > 1 && h->overlay_fn(h->overlay_user, PE_HIP_OVERLAY_INSTANCE, b, t, dt, nullptr, nullptr, nullptr) != 0)
+            return fail(h, PE_HIP_ERR_INTERNAL, "host-stamp overlay: the callback refused PE_HIP_OVERLAY_INSTANCE (it does not support batches)");
+        if(hc.rows) HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x + static_cast<size_t>(b) * hc.rows, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
         bool const iter = event == PE_HIP_OVERLAY_ITERATE;
         h->ov_a.assign(static_cast<size_t>(hc.n_ov_a), 0.0);
         h->ov_b.assign(static_cast<size_t>(hc.n_ov_b), 0.0);
@@ -196,9 +200,18 @@ namespace
         if(orc != 0) return fail(h, PE_HIP_ERR_INTERNAL, "host-stamp overlay: a model hook failed");
         if(iter)
         {
-            if(hc.n_ov_a) HIPCHK(h, hipMemcpy(h->V.dv + hc.dv_ova, h->ov_a.data(), static_cast<size_t>(hc.n_ov_a) * sizeof(double), hipMemcpyHostToDevice));
-            if(hc.n_ov_b) HIPCHK(h, hipMemcpy(h->V.dv + hc.dv_ovb, h->ov_b.data(), static_cast<size_t>(hc.n_ov_b) * sizeof(double), hipMemcpyHostToDevice));
+            double* dv = h->V.dv + static_cast<size_t>(b) * h->V.dv_len;
+            if(hc.n_ov_a) HIPCHK(h, hipMemcpy(dv + hc.dv_ova, h->ov_a.data(), static_cast<size_t>(hc.n_ov_a) * sizeof(double), hipMemcpyHostToDevice));
+            if(hc.n_ov_b) HIPCHK(h, hipMemcpy(dv + hc.dv_ovb, h->ov_b.data(), static_cast<size_t>(hc.n_ov_b) * sizeof(double), hipMemcpyHostToDevice));
         }
+        return PE_HIP_OK;
+    }
+    // the same for every instance of `mask` (null: all)
+    int overlay_call_all(pe_hip_engine* h, int event, int mode, double t, double dt, std::vector<int> const* mask)
+    {
+        for(int b = 0; b < h->hc.batch; ++b)
+            if(!mask || (*mask)[b])
+                if(int const rc = overlay_call(h, event, mode, t, dt, b); rc != PE_HIP_OK) return rc;
         return PE_HIP_OK;
     }
     bool has_overlay(pe_hip_engine const* h) { return h->overlay_fn && (h->hc.n_ov_a || h->hc.n_ov_b); }
@@ -855,7 +868,7 @@ namespace
         for(int it = 0; it < max_it && n_active > 0; ++it)
         {
             if(has_overlay(h))
-                if(int const rc = overlay_call(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step); rc != PE_HIP_OK) return rc;
+                if(int const rc = overlay_call_all(h, PE_HIP_OVERLAY_ITERATE, mode, t, last_step, &S.active); rc != PE_HIP_OK) return rc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             // (test knob PHY_ENGINE_HIP_FULL_STAMP=1: every iteration stamps everything -- the x-dependent-only path must match it bit for bit)
             static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
@@ -883,7 +896,7 @@ namespace
                     // hooks -- host-stamped models only (the built-in ones have none); a veto costs one more iteration
                     if(has_overlay(h) && h->hc.nonlinear)
                     {
-                        int const crc = overlay_call(h, PE_HIP_OVERLAY_CONVERGED, mode, t, last_step);
+                        int const crc = overlay_call(h, PE_HIP_OVERLAY_CONVERGED, mode, t, last_step, b);
                         if(crc == PE_HIP_OVERLAY_VETO) continue;
                         if(crc != PE_HIP_OK) return crc;
                     }
@@ -948,7 +961,7 @@ namespace
                 for(int b = 0; b < B; ++b)
                     if(!(*only)[b] && S.status[b] == PE_HIP_OK) S.status[b] = -1000;
             if(has_overlay(h) && !(skip_first && s == 0))
-                if(int const orc = overlay_call(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt); orc != PE_HIP_OK) return orc;
+                if(int const orc = overlay_call_all(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt, &S.active); orc != PE_HIP_OK) return orc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             if(!(skip_first && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
@@ -2053,6 +2066,7 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     if(!op.rl_engaged.empty()) HIPCHK(h, hipMemcpy(op.rl_engaged.data(), h->V.rl_engaged, op.rl_engaged.size() * sizeof(int), hipMemcpyDeviceToHost));
     if(has_overlay(h))
     {
+        if(hc.batch > 1) return fail(h, PE_HIP_ERR_ARG, "analyze_ac: a host-stamp overlay needs batch = 1 for small-signal analysis");
         // host-stamped models: their iterate_ac hooks stamp complex values at this omega around the operating point held in x
         op.ov_a.assign(2 * static_cast<size_t>(hc.n_ov_a), 0.0);
         op.ov_b.assign(2 * static_cast<size_t>(hc.n_ov_b), 0.0);

@@ -6,7 +6,8 @@
 // and -- the point of a file format -- the same bytes: keys and value encodings of :584-803 (save) / :805-1313 (load), the stable
 // graph ids of :107-322 (checkpoints find their nodes and models again after a reorder), the archive of archive.h, all on LevelDB's
 // on-disk format (kv_store.h: a fresh minimal implementation, not LevelDB).  tests/test_penl.py exchanges files with the REAL
-// reference in both directions (oracle/Makefile: ref_penl) and pins reference-written fixtures under tests/golden/penl/.
+// reference in both directions (the tool of tests/cpp/penl_tool.cpp built against either tree) and pins reference-written fixtures
+// under tests/golden/penl/.
 //
 // Keys (all values little endian; `uleb` = ULEB128, `str` = uleb length + bytes):
 //   meta/format_version u32=1 | meta/mode u8 | meta/structure_hash u64 | meta/uid_algo_version u32=1 | meta/flags u8 x4 {node state,

@@ -4,6 +4,7 @@ exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64):
   known_answers   own netlists with closed-form answers: the 3 V / 10 + 20 ohm string (3 V, 2 V, 0.1 A), RC charging to 1 - 1/e,
                   the diode operating point (KCL with the Shockley law; the real reference's 0.62944165 V)
   user_model_overlay  plug-in models with host hooks only (no device table): diode, capacitor with its own companion, cubic conductor
+  overlay_batch   the host-stamp overlay on a batch of three instances (PE_HIP_OVERLAY_INSTANCE, C ABI): equals three runs of one, bit for bit
   bridge_tr       config C2 through full_bridge_rectifier + a host-stamped user resistor
   dll_smoke       test/0008.dll/dll_main_smoke.cpp
   linear_models   the known answers of test/0005.models/{vccs_dc,vcvs_gain,cccs_dc,ccvs_dc,op_amp_follower,transformer_ratio,
@@ -19,7 +20,7 @@ import pytest
 from parity_common import ROOT
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["known_answers", "user_model_overlay", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
+TESTS = ["known_answers", "user_model_overlay", "overlay_batch", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")
