@@ -14,8 +14,9 @@
 //   model state, run time, structure} | circuit/env 10 x f64 | circuit/analyze_type u32 | circuit/analyzer | runtime/basic |
 //   nodes/count uleb | nodes/ground_uid u64 | nodes/<i>/uid u64 | nodes/<i>/state | nodes/ground 2 x f64 | models/count uleb |
 //   m/<i>/{model_name, identification_name, attrs, wrapper, pins, state, uid}
-// The device-resident simulation state (companion histories, junction state of every instance) is not part of the container: it has
-// its own checkpoint (pe_hip_checkpoint_save / _load, include/pe_hip.h), bit-exact on resume.
+// Additive (ignored by the reference, which looks keys up by name): runtime/pe_hip_state -- the device-resident simulation state of the
+// saved circuit (pe_hip_checkpoint_save, include/pe_hip.h: companion histories, junction / relay state), applied when the loaded circuit
+// next goes onto the device: a transient resumed from a container of this build continues bit for bit (tests/test_penl.py).
 //
 // Stable ids across builds.  The id algorithm is restated from the reference's text, but the reference's VALUES cannot be reproduced:
 // it hashes every edge's pin name through a std::string_view into a std::string that died at the end of the loop body that created it
@@ -456,6 +457,8 @@ namespace phy_engine::pe_nl_fileformat
             append_u8(v, static_cast<std::uint8_t>(c.cuda_policy));
             append_uleb128(v, c.cuda_node_threshold);
             put("runtime/basic", std::move(v));
+            // additive (the reference looks keys up by name and never sees it): the device-resident simulation state of this build
+            if(auto blob = c.device_state(); !blob.empty()) put("runtime/pe_hip_state", std::move(blob));
         }
         {
             std::string v;
@@ -664,6 +667,8 @@ namespace phy_engine::pe_nl_fileformat
                 c.cuda_node_threshold = static_cast<std::size_t>(thr);
                 // (the device engine of this circuit is built by its next analyze(): nothing is `prepared` in a freshly loaded object)
                 c.has_prepare = false;
+                c.pending_device_state.clear();
+                if(auto s3 = db.get("runtime/pe_hip_state", v); s3) c.pending_device_state.assign(v);
             }
 
         std::vector<::phy_engine::model::node_t*> id_to_node(static_cast<std::size_t>(node_count));
@@ -783,6 +788,7 @@ namespace phy_engine::pe_nl_fileformat
                     if(!st2 && opt.require_model_state) return st2;
                 }
         }
+        c.adopt_netlist_state();  // (a circuit already resident on the device is loaded again by its next analyze(): from this state)
         if(!has_node_state && checkpoint) return {};  // a checkpoint without node state leaves the node values alone
         for(std::uint64_t id = 0; id < node_count; ++id)
         {

@@ -1132,6 +1132,25 @@ namespace phy_engine
         // the last system the device assembled (built-in models and host-stamped ones together), for inspection only.
         ::phy_engine::MNA::MNA mna{};
         ::std::size_t mna_mirror_rows{2048};
+        // device-resident state handed over by pe_nl_fileformat::load (key runtime/pe_hip_state), applied when the circuit is next
+        // loaded onto the device; device_state() is what pe_nl_fileformat::save stores (empty: nothing resident)
+        ::std::string pending_device_state{};
+        // the netlist's node voltages / branch currents were changed from outside (a checkpoint applied by pe_nl_fileformat::load):
+        // the next analyze() loads the circuit onto the device again and resumes from them (and from pending_device_state)
+        void adopt_netlist_state() noexcept
+        {
+            loaded_ = false;
+            has_prepare = false;
+        }
+        ::std::string device_state() const
+        {
+            ::std::string blob;
+            ::std::size_t n = 0;
+            if(!gpu_ || !loaded_ || pe_hip_checkpoint_size(gpu_, &n) != PE_HIP_OK || n == 0) return blob;
+            blob.resize(n);
+            if(pe_hip_checkpoint_save(gpu_, blob.data(), n) != PE_HIP_OK) blob.clear();
+            return blob;
+        }
 
         // circuit.h:63-68,115-121: the reference chooses between its CPU LU and the CUDA solver per solve.  Kept for source
         // compatibility; this engine has ONE solver (the device), so auto_select and force_cuda mean the same and force_cpu makes
@@ -1532,6 +1551,14 @@ namespace phy_engine
                 for(auto* b: size_t_to_branch_p) x[node_counter + b->index] = b->current.real();
                 if(!x.empty() && pe_hip_set_solution(gpu_, 0, 1, x.data()) != PE_HIP_OK) return gpu_fail();
                 if(pe_hip_set_time(gpu_, tr_duration, last_step) != PE_HIP_OK) return gpu_fail();
+                // a PE-NL container written by this build carries the device-resident state of the circuit it saved (companion
+                // histories, junction / relay state, counters): a transient resumed from it continues bit for bit.  A blob that does
+                // not fit this circuit (another topology) is dropped -- the netlist state above is the fallback.
+                if(!pending_device_state.empty())
+                {
+                    (void)pe_hip_checkpoint_load(gpu_, pending_device_state.data(), pending_device_state.size());
+                    pending_device_state.clear();
+                }
             }
             else
             {

@@ -3,8 +3,9 @@
 // repository's headers (phy-engine_amd/include) and against the reference's (oracle/Makefile: ref_penl, with the reference's
 // vendored LevelDB), so that files written by one side are read by the other:
 //
-//   penl_tool save <path> <full|structure|runtime> <file|dir> [solve|zoo]   build the test circuit (solve: run its analysis first; zoo: one
-//                                                                         of every model instead, every attribute set), save it
+//   penl_tool save <path> <full|structure|runtime> <file|dir> [solve|zoo|tr]   build the test circuit (solve: run its analysis first; zoo: one
+//                                                                         of every model instead, every attribute set; tr: five transient
+//                                                                         steps before the save and five after it, dump = the final state), save it
 //   penl_tool dump <path> [lenient]                                       load <path> into an empty circuit, print a canonical dump
 //   penl_tool apply <checkpoint> [lenient]                                build the circuit (unsolved), apply a runtime-only checkpoint, dump
 //   penl_tool solve <path> [lenient]                                      load, analyze(), print the node voltages
@@ -350,6 +351,15 @@ int main(int argc, char** argv)
         else
             build(c);
         bool solved = false;
+        bool const tr = argc > 5 && std::strcmp(argv[5], "tr") == 0;
+        if(tr)
+        {
+            // five transient steps, save, five more: the dump printed is the UNINTERRUPTED run's -- `solve <path>` (load, five steps)
+            // must arrive at the same state
+            c.set_analyze_type(::phy_engine::analyze_type::TR);
+            if(!c.analyze()) return 3;
+            c.digital_clk();
+        }
         if(argc > 5 && std::strcmp(argv[5], "solve") == 0)
         {
             if(!c.analyze())
@@ -365,6 +375,12 @@ int main(int argc, char** argv)
         o.mode = std::strcmp(argv[3], "full") == 0 ? pf::export_mode::full : (std::strcmp(argv[3], "structure") == 0 ? pf::export_mode::structure_only : pf::export_mode::runtime_only);
         o.layout = std::strcmp(argv[4], "dir") == 0 ? pf::storage_layout::directory : pf::storage_layout::single_file;
         if(int const rc = report(pf::save(path, c, o), "save"); rc) return rc;
+        if(tr)
+        {
+            if(!c.analyze()) return 3;
+            c.digital_clk();
+            solved = true;
+        }
         dump(c, solved);
         return 0;
     }

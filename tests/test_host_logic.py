@@ -362,6 +362,47 @@ assert np.all(np.isfinite(eng.solution()[0]))
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
 
 
+def test_revived_instance_keeps_its_own_time_point_under_host_emulation(emu_lib):
+    """Round-2 advisor finding (medium): in a batch on the host-driven split schedule, an instance that failed and was rolled back in
+    call 1 is live again in call 2 -- at ITS time point, not the group's.  Two instances of the diode mesh, instance 1 driven hard
+    enough that a Newton limit of 2 iterations stops it early while instance 0 (diodes off) runs on; call 2 (limit lifted) must
+    leave each instance exactly where the same instance ends up when it is run ALONE through the same two calls: time, step count and
+    solution.  (Sources are evaluated at an instance's own t: solving the revived instance at the group's time would show here.)"""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+os.environ['PHY_ENGINE_HIP_SPLIT'] = '1'
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))
+import numpy as np
+import pe_load
+pe = pe_load.load()
+deck = pe.deck.rc_mesh(12, 12, 1, True)
+nvac = deck.count('VAC'); assert nvac == 1
+vp = [0.02, 2.0]
+def vac(amps):
+    return np.array([[[a, 2.0 * np.pi * 1e8, 0.0]] for a in amps])
+def two_calls(amps):
+    eng = pe.ffi.Engine(); eng.set_options(g_min=0.0, max_newton=2)
+    eng.load_deck(deck, batch=len(amps), overrides={{'VAC': vac(amps)}}); eng.reset()
+    st1 = eng.analyze_tr(1e-10, 12, check=False)
+    s1 = eng.state()
+    eng.set_options(g_min=0.0, max_newton=64)
+    st2 = eng.analyze_tr(1e-10, 5, check=False)
+    return st1, s1, st2, eng.state(), eng.solution()
+st1, s1, st2, s2, x = two_calls(vp)
+assert s1['status'][0] == 0 and s1['steps'][0] == 12, s1                      # instance 0 ran all 12 steps
+assert s1['status'][1] == pe.ffi.ERR_NO_CONVERGENCE and 0 < s1['steps'][1] < 12, s1   # instance 1 was stopped and rolled back
+assert st2['rc'] == 0 and st2['n_failed'] == 0, st2
+assert s2['steps'][0] == 17 and s2['steps'][1] == s1['steps'][1] + 5, s2       # each went on from its own time point
+assert abs(s2['t'][0] - 17e-10) < 1e-20 and abs(s2['t'][1] - (s1['steps'][1] + 5) * 1e-10) < 1e-20, s2
+for b in range(2):
+    a1, as1, a2, as2, ax = two_calls([vp[b]])
+    assert as1['steps'][0] == s1['steps'][b] and as2['steps'][0] == s2['steps'][b] and as2['t'][0] == s2['t'][b], (b, as1, as2)
+    assert np.array_equal(ax[0], x[b]), (b, float(np.max(np.abs(ax[0] - x[b]))))
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=600)
+
+
 def test_residual_safety_net_under_host_emulation(emu_lib):
     """Static pivoting with a safety net (the reference pivots partially, Eigen SparseLU.h:464-469): after every linear solve the
     normwise backward error is checked per instance; above residual_tol the solve is refined (correction solve on the residual),
