@@ -435,6 +435,8 @@ namespace
         so.wave_p = std::max(1, env_int("PHY_ENGINE_HIP_WAVE_P", so.wave_p));
         so.absorb_m = std::max(1, env_int("PHY_ENGINE_HIP_ABSORB_M", so.absorb_m));
         so.nd_leaf = std::max(2, env_int("PHY_ENGINE_HIP_ND_LEAF", so.nd_leaf));
+        so.relax_zero_frac = 0.01 * std::clamp(env_int("PHY_ENGINE_HIP_RELAX_X100", static_cast<int>(so.relax_zero_frac * 100.0 + 0.5)), 0, 100);
+        so.relax_small = std::max(1, env_int("PHY_ENGINE_HIP_RELAX_SMALL", so.relax_small));
         so.cut_factor = 0.1 * std::max(1, env_int("PHY_ENGINE_HIP_CUT_X10", static_cast<int>(so.cut_factor * 10.0)));
         so.max_pivots = std::clamp(env_int("PHY_ENGINE_HIP_MAX_PIVOTS", so.max_pivots), 1, 64);  // (the triangular solves keep one pivot per lane)
         so.n_parts = std::clamp(env_int("PHY_ENGINE_HIP_PARTS", so.n_parts), 1, 64);
