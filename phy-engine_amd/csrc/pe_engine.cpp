@@ -422,6 +422,16 @@ namespace
         so.quad = (four_per_cu && large && env_int("PHY_ENGINE_HIP_QUAD", 1) != 0) ? 1 : 0;
         if(so.quad)
         {
+            // Amalgamation re-swept WITH the lane-group kernel (profiles/sweep_r03_amalgamation.log): a front that absorption grows past
+            // order 32 drops out of the quad class, and with it every ancestor inside its wave subtree.  Absorbing only up to order 32 and
+            // forcing last-child merges only up to 4 pivots (8 before) leaves 933 of 995 wave fronts to the lane-group kernel on M10k (706
+            // of 814 before), 5 % fewer stored factor entries: launch pair -2.3 %, steps/s +1.8 % at 1 024 instances (three interleaved runs).
+            // (128 instances -- 16 parts -- do not gain: 31.8 k against 32.0 k steps/s; 256: +2 %.  From 192 instances on.)
+            if(batch >= 192)
+            {
+                so.absorb_m = 32;
+                so.relax_small = 4;
+            }
             // (the wave-front class keeps the geometry above: wave fronts that do not qualify for the lane-group kernel -- order 33..45, or
             //  above one -- stay with the per-instance wave phase, which is cheaper for them than the cooperative phase)
             so.quad_mid = env_int("PHY_ENGINE_HIP_MID", 0) != 0 ? 1 : 0;  // measured slower than the cooperative phase (pe_quad.hpp): off

@@ -686,7 +686,6 @@ namespace pe
             // Destination-centric assembly (pe_symbolic.hpp: build_assembly_lists): every LDS cell that receives anything from a
             // child is owned by ONE thread, which adds its sources in the children's order -- no barrier between children, and
             // the loads of all children (indices from the shared lists, values from this instance's arena) are in flight together.
-            int const n0 = V.gl_ptr[s + 1] - V.gl_ptr[s];
             int const r_lo = V.gl_rptr[s], R = V.gl_rptr[s + 1] - r_lo;
             unsigned short const* dst = V.gl_dst + V.gl_ptr[s];
             int const* sr = V.gl_src + V.gl_sptr[s];
