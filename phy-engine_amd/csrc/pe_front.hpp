@@ -1531,7 +1531,7 @@ namespace pe
         out4[2] = mx;
         out4[3] = mb;
     }
-    // Refinement residual of a small-signal AC point (pe_engine.cpp pe_hip_analyze_ac; the complex system in real-equivalent form):
+    // Refinement residual of a small-signal AC point (pe_engine_ac.cpp pe_hip_analyze_ac; the complex system in real-equivalent form):
     // r = b0 - A xacc with A as the last stamp assembled it, written into the instance's right-hand-side VALUE SLOTS
     // dv[rhs0 + row] -- the correction solve that follows gathers its right-hand side from there.  Returns this thread's worst
     // componentwise backward error |r_i| / (|b_i| + sum_j |a_ij x_j|).
@@ -1618,7 +1618,7 @@ namespace pe
             if(tm.sync_or(nonfinite)) return ST_SINGULAR;
             // Residual safety net: the iterate that is about to be ACCEPTED is checked (a linear solve, or the Newton iterate that passed
             // the convergence test).  The resident kernel only DETECTS an inaccurate solve (and fails the step like a Newton failure);
-            // the host then repeats it on the split schedule, whose host-driven loop refines / re-matches (pe_engine.cpp).
+            // the host then repeats it on the split schedule, whose host-driven loop refines / re-matches (pe_engine_newton.cpp).
             auto accurate = [&]() -> bool
             {
                 if(!(V.residual_tol > 0.0)) return true;

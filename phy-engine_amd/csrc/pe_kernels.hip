@@ -11,7 +11,7 @@
 //     (MINW = 2: <= 256 VGPRs, one 512-thread workgroup per CU; MINW = 4: 128 VGPRs, 256-thread workgroups, 4 per CU);
 //   * multi-workgroup schedule k_m2_*: one launch per phase and per top level of the assembly tree, an instance spread over
 //     n_parts workgroups + one workgroup per top front; the host drives the Newton loop from one flag word per instance
-//     (pe_engine.cpp run_m2_tr / m2_point).  Selected for few instances of a large circuit.
+//     (pe_engine_newton.cpp run_m2_tr / m2_point).  Selected for few instances of a large circuit.
 // Small-signal AC runs the same kernels on the real-equivalent 2N system (pe_ac.cpp).
 #include <hip/hip_runtime.h>
 
@@ -1275,7 +1275,7 @@ namespace pe
         return hipGetLastError();
     }
 
-    // ---- small-signal AC: iterative refinement of a frequency point entirely on the device (pe_engine.cpp pe_hip_analyze_ac)
+    // ---- small-signal AC: iterative refinement of a frequency point entirely on the device (pe_engine_ac.cpp pe_hip_analyze_ac)
     __global__ void __launch_bounds__(256) k_ac_residual(DevView V, double const* __restrict__ xacc, double const* __restrict__ b0, int rhs0, double* worst)
     {
         int const b = static_cast<int>(blockIdx.y);

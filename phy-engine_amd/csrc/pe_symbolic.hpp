@@ -21,7 +21,7 @@ namespace pe
 
     struct SymbolicOptions
     {
-        int nd_leaf{24};          // stop dissecting below this many vertices (large circuits: 10, pe_engine.cpp symbolic_options, profiles/sweep_r02_leaf.log)
+        int nd_leaf{24};          // stop dissecting below this many vertices (large circuits: 10, pe_engine_policy.cpp symbolic_options, profiles/sweep_r02_leaf.log)
         int relax_small{8};       // always merge a last child into its parent while the merged front has <= this many pivots
         double relax_zero_frac{0.30};  // otherwise merge only if the explicit zeros added stay below this fraction of the merged panel
         int max_pivots{48};       // never grow a front beyond this many pivots (chains are split)

@@ -331,7 +331,7 @@ def test_dc_then_tr_switches_symbolic(eng, oracle_mod):
 @pytest.mark.parametrize("name,tol,parts", [("mesh32_nl", NL, 6), ("mesh32_lin", LIN, 16), ("ladder_c1", LIN, 4), ("mesh100_nl", NL, 1),
                                             ("mesh100_nl", NL, 13), ("bridge_c2", NL, 2), ("mesh100_nl", NL, -1), ("mesh32_nl", NL, -1)])
 def test_golden_parity_multi_workgroup(name, tol, parts, monkeypatch):
-    """Same goldens through the split schedule (parts + top levels, one launch per phase: pe_engine.cpp run_m2_tr) and, with
+    """Same goldens through the split schedule (parts + top levels, one launch per phase: pe_engine_newton.cpp run_m2_tr) and, with
     parts = -1, through the resident single-workgroup kernel (PHY_ENGINE_HIP_SPLIT=0 / =1 override the size rule:
     circuits of >= 3000 rows run the split schedule, smaller ones the resident kernel)."""
     if parts < 0:
@@ -374,7 +374,7 @@ def test_multi_workgroup_batch_matches_single_workgroup(monkeypatch):
 @pytest.mark.parametrize("geometry", ["64", "128", "256", "1024"])
 @pytest.mark.parametrize("split", ["0", "auto"])
 def test_launch_geometries_on_large_circuit(geometry, split, monkeypatch):
-    """M10k golden under every launch geometry the batch-size policy selects (symbolic_options in pe_engine.cpp: 8 wavefronts x
+    """M10k golden under every launch geometry the batch-size policy selects (symbolic_options in pe_engine_policy.cpp: 8 wavefronts x
     1 workgroup per CU, 4 x 4 with 4 or 8 parts), each in the split schedule and in the resident kernel; 2 identical instances."""
     monkeypatch.setenv("PHY_ENGINE_HIP_GEOMETRY_BATCH", geometry)
     if split != "auto":

@@ -193,7 +193,7 @@ def emu_lib():
                                            "coupled_l_dc", "controlled_mix_tr", "nmos_cutoff_dc", "nmos_sat_dc", "nmos_triode_op",
                                            "cmos_inverter_tr", "bjt_amp_tr", "center_tap_ratio", "relay_ramp_tr")])
 def test_front_code_indexing_under_host_emulation(emu_lib, name, parts):
-    """Runs pe_front.hpp + pe_engine.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
+    """Runs pe_front.hpp + pe_engine*.cpp with a ONE-THREAD team in a subprocess against the reference goldens.
     parts > 1 = the multi-workgroup schedule (level-1 cut + top levels, one launch per phase); parts < 0 = the same
     with a small LDS so that the large-front code paths are exercised too.
     This validates indexing/orchestration only; the parity proper is tests/test_gpu_parity.py on the MI355X."""
