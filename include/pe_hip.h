@@ -171,6 +171,15 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
 int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* opt);
 int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out);
 
+/* Tuning knobs of ONE engine: the launch-geometry / symbolic-analysis parameters INTEGRATION.md lists as the PHY_ENGINE_HIP_* environment
+ * family (the counterpart of the reference's cuda_policy / cuda_node_threshold members plus its PHY_ENGINE_CUDA_* variables,
+ * circuit.h:63-68, benchmark/README.md:11-21), set per engine instead of per process: `name` with or without the PHY_ENGINE_HIP_
+ * prefix ("PARTS", "ABSORB_M", "SPLIT", ...).  A knob set here wins over the environment variable of the same name, which wins over the
+ * measured default; it takes effect at the next analysis of the resident circuit (the symbolic analysis is redone).  Test-only
+ * variables (…_TEST_*, …_FULL_STAMP, …_DUMP_SCHEDULE, …_LDS_BYTES) stay environment-only. */
+int pe_hip_set_knob(pe_hip_engine* h, const char* name, int value);
+int pe_hip_get_knob(pe_hip_engine* h, const char* name, int* value, int* is_set); /* what is set (engine, else environment); is_set may be NULL */
+
 /* digital_out of circult (circuit.h:102,509,1015-1022): ideal sources occupying the FIRST `count` branches.
  * Pass the drives before pe_hip_load_circuit() (they are part of the branch numbering).  On a loaded engine the same
  * drive set with new voltages updates in place; a different set invalidates the resident circuit (reload it). */

@@ -299,6 +299,30 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
     return PE_HIP_OK;
 }
 
+int pe_hip_set_knob(pe_hip_engine* h, const char* name, int value)
+{
+    if(!h || !name || !*name) return PE_HIP_ERR_ARG;
+    std::string key{name};
+    if(key.rfind("PHY_ENGINE_HIP_", 0) == 0) key.erase(0, 15);
+    if(key.empty()) return fail(h, PE_HIP_ERR_ARG, "set_knob: empty name");
+    h->knobs[key] = value;
+    h->sym_class = -1;  // the launch geometry and the symbolic analysis are chosen again at the next analysis
+    return PE_HIP_OK;
+}
+
+int pe_hip_get_knob(pe_hip_engine* h, const char* name, int* value, int* is_set)
+{
+    if(!h || !name || !value) return PE_HIP_ERR_ARG;
+    std::string key{name};
+    if(key.rfind("PHY_ENGINE_HIP_", 0) == 0) key.erase(0, 15);
+    auto const it = h->knobs.find(key);
+    char const* env = std::getenv(("PHY_ENGINE_HIP_" + key).c_str());
+    bool const set = it != h->knobs.end() || (env && *env);
+    if(is_set) *is_set = set ? 1 : 0;
+    *value = it != h->knobs.end() ? it->second : (env && *env ? std::atoi(env) : 0);
+    return PE_HIP_OK;
+}
+
 int pe_hip_set_overlay(pe_hip_engine* h, int n_cells, const int* rows, const int* cols, const double* representative, int n_rhs, const int* rhs_rows,
                        int nonlinear, pe_hip_overlay_fn fn, void* user)
 {

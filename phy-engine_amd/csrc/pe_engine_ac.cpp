@@ -21,6 +21,7 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     {
         if(!pe::build_ac_circuit(hc, A.circ, has_overlay(h) ? &h->overlay : nullptr)) return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: could not build the AC system");
         if(pe_hip_create(h->device, &A.eng) != PE_HIP_OK) return fail(h, PE_HIP_ERR_NO_DEVICE, "analyze_ac: " + std::string(pe_hip_last_error(nullptr)));
+        A.eng->knobs = h->knobs;  // (the real-equivalent system is analysed under the same tuning knobs)
         // The right-hand side of the device copy comes from one value slot per row: the host evaluates the sources' lists
         // and, for the refinement steps below, writes residuals there.
         {

@@ -28,6 +28,8 @@
 #include "pe_kernels.hpp"
 #include "pe_symbolic.hpp"
 
+#include <map>
+
 namespace pe_eng  // (Pool is a member type of the engine object: default visibility, header-only)
 {
     using clk = std::chrono::steady_clock;
@@ -87,6 +89,7 @@ struct pe_hip_engine
     std::string err;
     pe_hip_options opt{};
     int lds_limit{65536};
+    std::map<std::string, int> knobs;  // pe_hip_set_knob: this engine's overrides of the PHY_ENGINE_HIP_* tuning knobs (name without the prefix)
 
     // resident circuit
     bool loaded{};
@@ -176,6 +179,7 @@ namespace pe_eng PE_ENG_HIDDEN
     // pe_engine_policy.cpp
     bool split_launch(pe_hip_engine const* h);
     int env_int0(char const* name, int def);
+    int knob(pe_hip_engine const* h, char const* name, int def);
     int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch);
     pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve = 384, int force_resident = 0);
     int analyze_fitting(pe_hip_engine* h, int batch, int geometry_rows, int n, int const* rp, int const* ci, double const* vals, pe::Symbolic& S,

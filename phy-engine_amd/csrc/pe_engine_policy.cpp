@@ -13,9 +13,9 @@ namespace pe_eng PE_ENG_HIDDEN
     // takes milliseconds.  Small circuits stay in the resident kernel (a time step is microseconds there).
     bool split_launch(pe_hip_engine const* h)
     {
-        char const* v = std::getenv("PHY_ENGINE_HIP_SPLIT");  // knob: 1 = always split, 0 = never (resident kernel, one part)
-        if(v && *v == '1') return true;
-        if(v && *v == '0') return false;
+        int const v = knob(h, "SPLIT", -1);  // knob: 1 = always split, 0 = never (resident kernel, one part)
+        if(v == 1) return true;
+        if(v == 0) return false;
         if(h->overlay_fn && (h->hc.n_ov_a || h->hc.n_ov_b)) return true;  // host-stamped models: the host drives the Newton loop
         if(h->careful) return true;  // an inaccurate solve was detected: the host-driven loop refines / re-matches
         return h->V.n_parts > 1 || h->hc.rows >= 3000;
@@ -23,10 +23,10 @@ namespace pe_eng PE_ENG_HIDDEN
 
     // uploads symbolic arrays + allocates per-instance factor storage into `pool`, fills the symbolic part of V
     // test knob: choose the launch geometry as if the batch had this many instances
-    int geometry_batch(int batch)
+    int geometry_batch(pe_hip_engine const* h, int batch)
     {
-        char const* v = std::getenv("PHY_ENGINE_HIP_GEOMETRY_BATCH");
-        return v && *v ? std::max(1, std::atoi(v)) : batch;
+        int const v = knob(h, "GEOMETRY_BATCH", 0);
+        return v > 0 ? v : batch;
     }
 
 
@@ -101,8 +101,8 @@ namespace pe_eng PE_ENG_HIDDEN
         // the one-workgroup-per-CU geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances
         // <= CUs + 25 %).  Such a workgroup owns its CU's LDS: whole-front layout up to order ~141, chain links continued in LDS.
         {
-            bool const wide_knob = env_int0("PHY_ENGINE_HIP_WIDE_TOP", 1) != 0;
-            bool const chain_lds = env_int0("PHY_ENGINE_HIP_TOP_CHAIN_LDS", 1) != 0;  // developer knob: 0 = round 2's layout of the top fronts
+            bool const wide_knob = knob(h, "WIDE_TOP", 1) != 0;
+            bool const chain_lds = knob(h, "TOP_CHAIN_LDS", 1) != 0;  // developer knob: 0 = round 2's layout of the top fronts
             long long const whole_cu = h->lds_limit / 8 - 160 - 8;
             for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * batch <= 320)) ? 1 : 0;
             V.lds_top_doubles = chain_lds ? static_cast<int>(std::max<long long>(V.lds_doubles, whole_cu)) : V.lds_doubles;
@@ -140,8 +140,8 @@ namespace pe_eng PE_ENG_HIDDEN
             // a quad addresses its four instances by 32-bit byte offsets from the first one: every per-instance array must leave room
             // for at least one instance inside 4 GiB (else the wave fronts fall back to the per-instance path of factor_part)
             long long const stride = 8 * std::max({static_cast<long long>(S.nnzA), V.factor_doubles, V.arena_doubles, static_cast<long long>(S.n)});
-            V.quad = stride < (1ll << 31) ? (env_int0("PHY_ENGINE_HIP_QUAD", 1) | 1) : 0;
-            V.quad_back = (V.quad && env_int0("PHY_ENGINE_HIP_QUAD_BACK", 1) != 0) ? 1 : 0;  // the same fronts' backward pass on the lane-group kernel
+            V.quad = stride < (1ll << 31) ? (knob(h, "QUAD", 1) | 1) : 0;
+            V.quad_back = (V.quad && knob(h, "QUAD_BACK", 1) != 0) ? 1 : 0;  // the same fronts' backward pass on the lane-group kernel
         }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
@@ -154,16 +154,23 @@ namespace pe_eng PE_ENG_HIDDEN
         char const* v = std::getenv(name);
         return v && *v ? std::atoi(v) : def;
     }
+    // a tuning knob of THIS engine: pe_hip_set_knob() first, then the process environment (PHY_ENGINE_HIP_<name>), then the default
+    int knob(pe_hip_engine const* h, char const* name, int def)
+    {
+        if(h)
+            if(auto it = h->knobs.find(name); it != h->knobs.end()) return it->second;
+        return env_int0((std::string("PHY_ENGINE_HIP_") + name).c_str(), def);
+    }
 
     pe::SymbolicOptions symbolic_options(pe_hip_engine const* h, int batch_in, int rows, int panel_reserve, int force_resident)
     {
-        int const batch = geometry_batch(batch_in);
+        int const batch = geometry_batch(h, batch_in);
         pe::SymbolicOptions so{};
         // Workgroup geometry by batch size (measured on MI355X, profiles/ and scripts/sweep_split_*.sh).
         // Large circuits run the split schedule (one launch per phase): from ~100 instances on, 256-thread workgroups at four per
         // CU with every instance cut into 4 (8, 16) parts -- >= 1024 workgroups for the low-register kernels; fewer instances keep one
         // big workgroup per CU and more parts.  Small circuits run the resident kernel: geometry by the batch alone.
-        bool const large = rows >= 3000 && env_int0("PHY_ENGINE_HIP_SPLIT", -1) != 0;
+        bool const large = rows >= 3000 && knob(h, "SPLIT", -1) != 0;
         bool const four_per_cu = large ? batch >= 96 : batch >= 768;
         if(four_per_cu)
         {
@@ -198,11 +205,7 @@ namespace pe_eng PE_ENG_HIDDEN
                               // small circuits keep 24 (their whole graph is one minimum-degree leaf, as validated by every golden)
         }
         // tuning knobs (PHY_ENGINE_HIP_* family, SURVEY.md 5 "Config / flags")
-        auto env_int = [](char const* name, int def)
-        {
-            char const* v = std::getenv(name);
-            return v && *v ? std::atoi(v) : def;
-        };
+        auto env_int = [h](char const* name, int def) { return knob(h, name + 15, def); };  // (name without its PHY_ENGINE_HIP_ prefix)
         // the wave fronts of a large sweep run four instances per wavefront on the lane-group kernel (pe_quad.hpp): fronts of order
         // <= 32 with <= 16 pivots; larger ones stay with the cooperative phase
         so.quad = (four_per_cu && large && env_int("PHY_ENGINE_HIP_QUAD", 1) != 0) ? 1 : 0;

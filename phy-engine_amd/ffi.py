@@ -23,7 +23,7 @@ OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL, ERR_
 
 EXPORTS = [
     "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real",
-    "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_update_param",
+    "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_set_knob", "pe_hip_get_knob", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_measure_hbm_ceiling", "pe_hip_get_safety_net_counters", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
     "pe_hip_analyze_pattern_fronts", "pe_hip_get_phase_clocks", "pe_hip_get_phase_clocks_ex", "pe_hip_analyze_ac", "pe_hip_get_solution_ac", "pe_hip_checkpoint_size", "pe_hip_checkpoint_save", "pe_hip_checkpoint_load", "pe_hip_set_time",
@@ -238,6 +238,15 @@ class Engine:
     def set_options(self, g_min=0.0, v_abstol=0.0, v_reltol=0.0, i_abstol=0.0, i_reltol=0.0, max_newton=0, refactor_every_solve=1, r_open=0.0, residual_tol=0.0):
         o = Options(v_abstol, v_reltol, i_abstol, i_reltol, g_min, max_newton, refactor_every_solve, r_open, residual_tol)
         self._chk(lib().pe_hip_set_options(self._h, C.byref(o)))
+
+    def set_knob(self, name, value):
+        """one of the PHY_ENGINE_HIP_* tuning knobs for THIS engine; takes effect at the next analysis"""
+        self._chk(lib().pe_hip_set_knob(self._h, name.encode(), int(value)))
+
+    def get_knob(self, name):
+        v, s = C.c_int(0), C.c_int(0)
+        self._chk(lib().pe_hip_get_knob(self._h, name.encode(), C.byref(v), C.byref(s)))
+        return v.value if s.value else None
 
     def set_digital_drives(self, nodes, volts):
         n = np.ascontiguousarray(nodes, dtype=np.int32)

@@ -362,6 +362,39 @@ assert np.all(np.isfinite(eng.solution()[0]))
     subprocess.run(["python3", "-c", code], check=True, timeout=300)
 
 
+def test_tuning_knobs_are_per_engine_under_host_emulation(emu_lib):
+    """pe_hip_set_knob / pe_hip_get_knob (include/pe_hip.h): the PHY_ENGINE_HIP_* family per ENGINE instead of per process -- two engines
+    of one process run the same circuit under different schedules (parts of the split schedule), an engine knob wins over the
+    environment variable, a knob set after the first analysis takes effect at the next one, and the results agree."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+os.environ['PHY_ENGINE_HIP_PARTS'] = '2'
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, 'tests'))
+import numpy as np
+import pe_load
+pe = pe_load.load()
+deck = pe.deck.rc_mesh(12, 12, 1, True)
+def engine(**knobs):
+    e = pe.ffi.Engine(); e.set_options(g_min=0.0)
+    for k, v in knobs.items(): e.set_knob(k, v)
+    e.load_deck(deck); e.reset(); e.analyze_tr(1e-10, 3)
+    return e
+a = engine(SPLIT=1, PARTS=3)
+b = engine(PHY_ENGINE_HIP_SPLIT=1)            # (the prefix is accepted; PARTS comes from the environment: 2)
+c = engine(SPLIT=0)
+assert a.info()['n_parts'] == 3 and b.info()['n_parts'] == 2 and c.info()['n_parts'] == 1, (a.info()['n_parts'], b.info()['n_parts'], c.info()['n_parts'])
+assert a.get_knob('PARTS') == 3 and b.get_knob('PARTS') == 2 and a.get_knob('ABSORB_M') is None
+xa, xb, xc = a.solution()[0], b.solution()[0], c.solution()[0]
+assert np.max(np.abs(xa - xc)) < 1e-9 and np.max(np.abs(xb - xc)) < 1e-9
+c.set_knob('SPLIT', 1); c.set_knob('PARTS', 4)   # resident circuit: re-analysed at the next analysis, the transient continues
+c.analyze_tr(1e-10, 2); a.analyze_tr(1e-10, 2)
+assert c.info()['n_parts'] == 4
+assert np.max(np.abs(c.solution()[0] - a.solution()[0])) < 1e-9
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=600)
+
+
 def test_revived_instance_keeps_its_own_time_point_under_host_emulation(emu_lib):
     """Round-2 advisor finding (medium): in a batch on the host-driven split schedule, an instance that failed and was rolled back in
     call 1 is live again in call 2 -- at ITS time point, not the group's.  Two instances of the diode mesh, instance 1 driven hard
