@@ -400,19 +400,23 @@ namespace pe
     // ------------------------------------------------------------------------------------------------
     // MNA assembly: every A slot / RHS row gathers its contributions in model order (deterministic)
     // ------------------------------------------------------------------------------------------------
+#ifndef PE_STAMP_UN
+    #define PE_STAMP_UN 8  // slots per thread in flight in the stamp kernels of the split schedule (their own launch: registers to spare)
+#endif
     // out[s] = sum over the contribution list of slot s, in list order; four slots per thread in flight (the three
     // dependent loads ptr -> src -> dv of one slot would otherwise be fully exposed)
     // (t0, T): this thread's index and the thread count of the group that shares the slot range [lo, hi)
     // `list` != null: the slots are list[lo .. n) instead of lo .. n
+    template <int UN = 4>
     PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n, int const* list = nullptr)
     {
-        for(int base = lo + t0; base < n; base += 4 * T)
+        for(int base = lo + t0; base < n; base += UN * T)
         {
-            int slot[4];
-            int e[4], end[4];
-            double acc[4];
+            int slot[UN];
+            int e[UN], end[UN];
+            double acc[UN];
 #pragma unroll
-            for(int q = 0; q < 4; ++q)
+            for(int q = 0; q < UN; ++q)
             {
                 int const k = base + q * T;
                 bool const ok = k < n;
@@ -426,14 +430,14 @@ namespace pe
             while(more)
             {
                 more = false;
-                int sr[4];
+                int sr[UN];
 #pragma unroll
-                for(int q = 0; q < 4; ++q) sr[q] = e[q] < end[q] ? src[e[q]] : -1;
-                double v[4];
+                for(int q = 0; q < UN; ++q) sr[q] = e[q] < end[q] ? src[e[q]] : -1;
+                double v[UN];
 #pragma unroll
-                for(int q = 0; q < 4; ++q) v[q] = dv[sr[q] >= 0 ? sr[q] >> 1 : 0];
+                for(int q = 0; q < UN; ++q) v[q] = dv[sr[q] >= 0 ? sr[q] >> 1 : 0];
 #pragma unroll
-                for(int q = 0; q < 4; ++q)
+                for(int q = 0; q < UN; ++q)
                     if(sr[q] >= 0)
                     {
                         acc[q] = (sr[q] & 1) ? acc[q] - v[q] : acc[q] + v[q];
@@ -442,7 +446,7 @@ namespace pe
                     }
             }
 #pragma unroll
-            for(int q = 0; q < 4; ++q)
+            for(int q = 0; q < UN; ++q)
                 if(base + q * T < n) out[slot[q]] = acc[q];
         }
     }
@@ -470,9 +474,9 @@ namespace pe
         };
         int lo, hi;
         range(V.n_dyn_a, lo, hi);
-        gather_contributions(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi, V.dyn_a);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi, V.dyn_a);
         range(V.n_dyn_b, lo, hi);
-        gather_contributions(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b);
     }
     PE_DEV void stamp_chunk(DevView const& V, int b, int g, int G, int t0, int T)
     {
@@ -485,9 +489,9 @@ namespace pe
         };
         int lo, hi;
         range(V.nnzA, lo, hi);
-        gather_contributions(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi);
         range(V.rows, lo, hi);
-        gather_contributions(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi);
     }
 
     // ================================================================================================

@@ -1075,6 +1075,8 @@ namespace pe
     // batches; few instances spread over more workgroups (these kernels are gathers: latency-bound at low occupancy)
     static int grid_per_instance(DevView const& V)
     {
+        static int const forced = getenv_int("PHY_ENGINE_HIP_EW_GRID", 0);  // developer knob (sweeps): workgroups per instance, as given
+        if(forced > 0) return forced;
         int const by_rows = (V.rows + 2047) / 2048, fine = (V.rows + 255) / 256, want = 512 / (V.batch > 0 ? V.batch : 1);
         int g = by_rows > (want < fine ? want : fine) ? by_rows : (want < fine ? want : fine);
         return g < 1 ? 1 : (g > 64 ? 64 : g);
