@@ -42,6 +42,10 @@
 #ifndef PE_QUAD_LDS_STACK
     #define PE_QUAD_LDS_STACK 0
 #endif
+// columns per wavefront-uniform skip test of the child loop (4 = one word of the child's column bytes, 8 = round 3's first version)
+#ifndef PE_QUAD_COLS
+    #define PE_QUAD_COLS 8
+#endif
 #if defined(__HIPCC__)
     #define PEQ_DEV __device__ __forceinline__
 #else
@@ -214,13 +218,18 @@ namespace pe
                             vu const ci = (L.w[s2][M / 4 + grp] >> (8 * (e & 3))) & 255u;
                             voff[s2] = cx.offR + (X::sel(ci != 0u, ci + static_cast<unsigned>(sp - 1), vu(static_cast<unsigned>(V.q_zero_off))) << 3);
                         }
+                        // (one wavefront-uniform skip per group of PE_QUAD_COLS columns the child does not touch at all.  Measured and not
+                        //  kept, profiles/r03_ab_runs.log ab8 / ab9: a second skip per row set none of the child's rows lands in -- the
+                        //  condition inside the column loop costs the launch pair +9 %: every branch ends a batch of loads in flight)
 #pragma unroll
-                        for(int C0 = 0; C0 < M; C0 += 8)
+                        for(int C0 = 0; C0 < M; C0 += PE_QUAD_COLS)
                         {
-                            if((cm[C0 >> 2] | cm[(C0 >> 2) + 1]) != 0u)  // (a group of 8 columns the child does not touch at all: skipped)
+                            unsigned touched = cm[C0 >> 2];
+                            if constexpr(PE_QUAD_COLS == 8) touched |= cm[(C0 >> 2) + 1];
+                            if(touched != 0u)
                             {
 #pragma unroll
-                                for(int C = C0; C < C0 + 8; ++C)
+                                for(int C = C0; C < C0 + PE_QUAD_COLS; ++C)
                                 {
                                     unsigned const cj = (cm[C >> 2] >> (8 * (C & 3))) & 255u;
                                     unsigned const shift = (cj ? cj - 1u : 0u) * ucb;
