@@ -43,6 +43,9 @@
     #define PE_QUAD_LDS_STACK 0
 #endif
 // columns per wavefront-uniform skip test of the child loop (4 = one word of the child's column bytes, 8 = round 3's first version)
+#ifndef PE_QUAD_ELIM_GUARD
+    #define PE_QUAD_ELIM_GUARD 1
+#endif
 #ifndef PE_QUAD_COLS
     #define PE_QUAD_COLS 8
 #endif
@@ -224,12 +227,14 @@ namespace pe
 #pragma unroll
                         for(int C0 = 0; C0 < M; C0 += PE_QUAD_COLS)
                         {
-                            unsigned touched = cm[C0 >> 2];
-                            if constexpr(PE_QUAD_COLS == 8) touched |= cm[(C0 >> 2) + 1];
+                            unsigned touched = 0u;
+#pragma unroll
+                            for(int j = 0; j < PE_QUAD_COLS / 4; ++j)
+                                if((C0 >> 2) + j < M / 4) touched |= cm[(C0 >> 2) + j];
                             if(touched != 0u)
                             {
 #pragma unroll
-                                for(int C = C0; C < C0 + PE_QUAD_COLS; ++C)
+                                for(int C = C0; C < C0 + PE_QUAD_COLS && C < M; ++C)
                                 {
                                     unsigned const cj = (cm[C >> 2] >> (8 * (C & 3))) & 255u;
                                     unsigned const shift = (cj ? cj - 1u : 0u) * ucb;
@@ -273,7 +278,9 @@ namespace pe
 #pragma unroll
                 for(int C0 = 0; C0 < M; C0 += 4)
                 {
-                    if(C0 + 3 > kk && C0 < m)
+                    // (C0 + 3 > kk folds at compile time; the run-time guard skips the groups of 4 columns beyond the front's order -- they
+                    //  hold zeros and are never stored.  PE_QUAD_ELIM_GUARD 0: no guard, those FMAs run on the zeros)
+                    if(C0 + 3 > kk && (!PE_QUAD_ELIM_GUARD || C0 < m))
                     {
 #pragma unroll
                         for(int C = C0; C < C0 + 4; ++C)
