@@ -43,6 +43,9 @@
     #define PE_QUAD_LDS_STACK 0
 #endif
 // columns per wavefront-uniform skip test of the child loop (4 = one word of the child's column bytes, 8 = round 3's first version)
+#ifndef PE_QUAD_BACK_LAZY_FENCE
+    #define PE_QUAD_BACK_LAZY_FENCE 1
+#endif
 #ifndef PE_QUAD_ELIM_GUARD
     #define PE_QUAD_ELIM_GUARD 1
 #endif
@@ -891,7 +894,9 @@ namespace pe
                     for(int k = K; k < K + 4; ++k) ucol[k] = vd(0.0);
                 }
             }
-            X::fence();  // the unknowns of the parent (the front before in this walk, or an earlier launch) are in memory
+            // the unknowns this front reads are in memory: behind a fence only if this wavefront wrote one of them since its last fence
+            // (blk[6], pe_symbolic.cpp) -- else the loads above and below go out together, one memory round trip instead of two
+            if(blk[6] || !PE_QUAD_BACK_LAZY_FENCE) X::fence();
             vd const wi = X::ld(baseW, offW + static_cast<unsigned>(c0) * 8u + ro);
             vd acc[4] = {vd(0.0), vd(0.0), vd(0.0), vd(0.0)};
 #pragma unroll

@@ -1172,10 +1172,33 @@ namespace pe
                     if(S.f_quad[S.wave_list[i]]) lists[static_cast<size_t>(part) * W + w].push_back(S.wave_list[i]);
         build_quad_program(S, lists, S.q_lds_doubles, S.q_prog, S.q_lists, S.q_lane);
         S.q_bprog.clear();
+        // owner front of every pivot column: a front of the backward walk reads the unknowns of its update rows, i.e. of the fronts that
+        // own those columns.  It needs the wavefront's fence only if one of them was written by this wavefront since its last fence
+        // (the front right before it in the walk, typically its parent); unknowns from earlier launches or from behind an earlier fence
+        // are in memory already -- q[6] tells (half of the fronts of M10k: a first child right behind its parent yes, its siblings no).
+        std::vector<int> col_owner(static_cast<size_t>(S.n), -1);
+        for(int s = 0; s < S.nfronts; ++s)
+            for(int c = 0; c < S.f_p[s]; ++c) col_owner[static_cast<size_t>(S.f_col0[s] + c)] = s;
+        std::vector<char> pending(static_cast<size_t>(S.nfronts), 0);
         for(auto const& lst: lists)  // (q_lists[2 L + 1] fronts of list L, stored back to back in list order: block index = fronts before it)
+        {
+            std::vector<int> since_fence;
             for(auto it = lst.rbegin(); it != lst.rend(); ++it)
             {
                 int const s = *it;
+                bool need = it == lst.rbegin();
+                for(int j = 0; j < S.f_u[s] && !need; ++j)
+                {
+                    int const o = col_owner[static_cast<size_t>(S.f_rows[S.f_rows_ptr[s] + j])];
+                    need = o >= 0 && pending[static_cast<size_t>(o)];
+                }
+                if(need)
+                {
+                    for(int t: since_fence) pending[static_cast<size_t>(t)] = 0;
+                    since_fence.clear();
+                }
+                pending[static_cast<size_t>(s)] = 1;
+                since_fence.push_back(s);
                 size_t const h = S.q_bprog.size();
                 S.q_bprog.resize(h + Symbolic::Q_BACK, 0);
                 int* q = S.q_bprog.data() + h;
@@ -1185,8 +1208,11 @@ namespace pe
                 q[3] = S.f_u[s];
                 q[4] = static_cast<int>(S.f_lptr[s] & 0xffffffffll);
                 q[5] = static_cast<int>(S.f_lptr[s] >> 32);
+                q[6] = need ? 1 : 0;
                 for(int j = 0; j < S.f_u[s]; ++j) q[8 + j] = S.f_rows[S.f_rows_ptr[s] + j];
             }
+            for(int t: since_fence) pending[static_cast<size_t>(t)] = 0;
+        }
         // MID fronts: the subtrees of kind-3 fronts inside a part's cooperative list, dealt out to W lists per part (longest first)
         S.n_mid = 0;
         std::vector<std::vector<int>> mlists(static_cast<size_t>(K) * W);
