@@ -264,6 +264,7 @@ void pe_hip_destroy(pe_hip_engine* h)
     (void)hipStreamDestroy(h->stream);
     if(h->pin_active) (void)hipHostFree(h->pin_active);
     if(h->pin_flags) (void)hipHostFree(h->pin_flags);
+    if(h->pub_host) (void)hipHostFree(h->pub_host);
     delete h;
 }
 

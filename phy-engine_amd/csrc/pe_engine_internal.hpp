@@ -29,6 +29,7 @@
 #include "pe_symbolic.hpp"
 
 #include <map>
+#include <thread>
 
 namespace pe_eng  // (Pool is a member type of the engine object: default visibility, header-only)
 {
@@ -108,6 +109,11 @@ struct pe_hip_engine
     int* pin_active{};
     int* pin_flags{};
     size_t pin_cap{};
+    // results published by the last launch of an iteration straight into pinned host memory (k_m2_publish): [sequence number][flags][norms]
+    void* pub_host{};
+    void* pub_dev{};  // the same memory as the device sees it
+    size_t pub_cap{};
+    unsigned long long pub_seq{};
     std::vector<int> active_dev;
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
     size_t stats_doubles{};

@@ -154,16 +154,78 @@ namespace pe_eng PE_ENG_HIDDEN
         return PE_HIP_OK;
     }
 
+    // The same without a copy command: the iteration's last launch (k_m2_publish) writes flags + residual norms into pinned host memory
+    // and then a sequence number; the host polls that word.  Falls back to the stream's completion if the word does not arrive (a failed
+    // launch): the caller then sees the error of the synchronisation.
+    struct Published
+    {
+        unsigned long long* seq;
+        int* flags;
+        double* eta;
+    };
+    Published pub_view(void* base, size_t B)
+    {
+        auto* p = static_cast<char*>(base);
+        return {reinterpret_cast<unsigned long long*>(p), reinterpret_cast<int*>(p + 64), reinterpret_cast<double*>(p + 64 + ((B * sizeof(int) + 63) / 64) * 64)};
+    }
+    int ensure_published(pe_hip_engine* h, size_t B)
+    {
+        size_t const need = 64 + ((B * sizeof(int) + 63) / 64) * 64 + 4 * B * sizeof(double);
+        if(h->pub_cap >= need) return PE_HIP_OK;
+        if(h->pub_host) (void)hipHostFree(h->pub_host);
+        h->pub_host = h->pub_dev = nullptr;
+        h->pub_cap = 0;
+        HIPCHK(h, hipHostMalloc(&h->pub_host, need, hipHostMallocDefault));
+        HIPCHK(h, hipHostGetDevicePointer(&h->pub_dev, h->pub_host, 0));
+        std::memset(h->pub_host, 0, need);
+        h->pub_cap = need;
+        return PE_HIP_OK;
+    }
+    // launches the publication of the iteration just enqueued and waits for it; `eta` (4 doubles per instance) may be null
+    int publish_and_wait(pe_hip_engine* h, std::vector<int>& flags, std::vector<double>* eta)
+    {
+        size_t const B = flags.size();
+        if(int const rc = ensure_published(h, B); rc != PE_HIP_OK) return rc;
+        auto const host = pub_view(h->pub_host, B), dev = pub_view(h->pub_dev, B);
+        unsigned long long const seq = ++h->pub_seq;
+        HIPCHK(h, pe::launch_m2_publish(h->stream, h->V, dev.flags, dev.eta, dev.seq, seq));
+        for(unsigned spins = 0; __atomic_load_n(host.seq, __ATOMIC_ACQUIRE) != seq; ++spins)
+        {
+            if((spins & 1023u) == 1023u)
+            {
+                hipError_t const q = hipStreamQuery(h->stream);
+                if(q == hipSuccess)
+                {
+                    if(__atomic_load_n(host.seq, __ATOMIC_ACQUIRE) == seq) break;
+                    return fail(h, PE_HIP_ERR_INTERNAL, "the iteration's results were not published (k_m2_publish did not run)");
+                }
+                if(q != hipErrorNotReady) HIPCHK(h, q);
+                if(spins > (1u << 16)) std::this_thread::yield();  // (a long iteration of a large sweep: leave the core to others)
+            }
+        }
+        std::copy(host.flags, host.flags + B, flags.begin());
+        if(eta && h->V.residual_tol > 0.0) eta->assign(host.eta, host.eta + 4 * B);
+        return PE_HIP_OK;
+    }
+
     // Residual safety net on the host-driven schedule.  The iteration just launched left the four norms of every active instance's
     // solve in eta_acc.  Instances above the tolerance get up to two rounds of iterative refinement (launch_m2_refine: active =
     // exactly those); their flags are then the Newton / finiteness bits of the corrected x.  What refinement cannot repair leaves
     // the iteration as PE_HIP_ERR_INACCURATE (the caller re-matches on that instance's values and retries the step).
-    int m2_check_residuals(pe_hip_engine* h, M2State& S, std::vector<int>& result, int& n_active)
+    // `published`: the norms of this iteration as k_m2_publish handed them over (empty: read them from the device)
+    int m2_check_residuals(pe_hip_engine* h, M2State& S, std::vector<int>& result, int& n_active, std::vector<double> const& published)
     {
         int const B = h->hc.batch;
         std::vector<double> eta(static_cast<size_t>(B) * 4);
+        bool first = published.size() == eta.size();
         auto pull_eta = [&]() -> int
         {
+            if(first)  // (the iteration's own norms came with its flags; later calls follow a refinement launch)
+            {
+                eta = published;
+                first = false;
+                return PE_HIP_OK;
+            }
             HIPCHK(h, hipMemcpy(eta.data(), h->V.eta_acc, eta.size() * sizeof(double), hipMemcpyDeviceToHost));
             return PE_HIP_OK;
         };
@@ -235,7 +297,16 @@ namespace pe_eng PE_ENG_HIDDEN
             static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
             HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0 && !full_stamp));
             ++launches;
-            if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK) return drc;  // (synchronises the stream)
+            // flags + residual norms of this iteration: published into pinned host memory by the iteration's last launch and polled
+            // (no copy command, no stream synchronisation); PHY_ENGINE_HIP_PUBLISH=0: the copy + synchronise of rounds 1-2
+            static bool const use_publish = env_int0("PHY_ENGINE_HIP_PUBLISH", 1) != 0;
+            std::vector<double> eta_now;
+            if(use_publish)
+            {
+                if(int const prc = publish_and_wait(h, S.flags, &eta_now); prc != PE_HIP_OK) return prc;
+            }
+            else if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK)
+                return drc;  // (synchronises the stream)
             {
                 float kms = 0.f;
                 if(hipEventElapsedTime(&kms, h->evk0, h->evk1) == hipSuccess)
@@ -245,7 +316,7 @@ namespace pe_eng PE_ENG_HIDDEN
                 }
             }
             if(h->V.residual_tol > 0.0)
-                if(int const rrc = m2_check_residuals(h, S, result, n_active); rrc != PE_HIP_OK) return rrc;
+                if(int const rrc = m2_check_residuals(h, S, result, n_active, eta_now); rrc != PE_HIP_OK) return rrc;
             for(int b = 0; b < B; ++b)
             {
                 if(!S.active[b]) continue;

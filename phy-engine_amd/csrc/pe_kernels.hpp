@@ -24,6 +24,8 @@ namespace pe
     hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes);
     // one round of iterative refinement of the active instances' last solve + re-check (residual safety net, pe_front.hpp)
     hipError_t launch_m2_refine(hipStream_t st, DevView const& V);
+    // flags + residual norms of the iteration just launched -> pinned host memory, then `seq` into *pub_seq (device-visible pointers)
+    hipError_t launch_m2_publish(hipStream_t st, DevView const& V, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq);
     // small-signal AC refinement on the device (pe_front.hpp ac_residual): r = b0 - A xacc of every instance into its right-hand-side
     // value slots dv[rhs0 ..), *worst (device, one double) = max componentwise backward error over all instances
     hipError_t launch_ac_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, int rhs0, double* worst);

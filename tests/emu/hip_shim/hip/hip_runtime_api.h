@@ -9,7 +9,7 @@
 #include <cstring>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInsufficientDriver = 35, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInsufficientDriver = 35, hipErrorNotReady = 600, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101 };
 typedef struct emu_stream* hipStream_t;
 struct emu_event { std::chrono::steady_clock::time_point t; };
 typedef emu_event* hipEvent_t;
@@ -26,6 +26,8 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 constexpr unsigned hipHostMallocDefault = 0;
 inline hipError_t hipHostMalloc(void** p, size_t b, unsigned) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t b) { std::memset(p, v, b); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t b, hipStream_t) { std::memset(p, v, b); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t b, hipMemcpyKind) { std::memcpy(d, s, b); return hipSuccess; }

@@ -294,6 +294,15 @@ namespace pe
         }
         return hipSuccess;
     }
+    hipError_t launch_m2_publish(hipStream_t, DevView const& V, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq)
+    {
+        for(int b = 0; b < V.batch; ++b) pub_flags[b] = V.flags[b];
+        if(V.residual_tol > 0.0)
+            for(int i = 0; i < 4 * V.batch; ++i) pub_eta[i] = V.eta_acc[i];
+        *pub_seq = seq;
+        return hipSuccess;
+    }
+
     hipError_t launch_m2_refine(hipStream_t, DevView const& V)
     {
         std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
