@@ -115,3 +115,18 @@ def adversarial_pivot_sweep():
     rr = np.array([[p[0] for k, _, p in d.devices if k == "R"] for d in (d0, d1)])[:, :, None]
     sw = np.array([[p[0] for k, _, p in d.devices if k == "SW"] for d in (d0, d1)])[:, :, None]
     return d0, d1, {"R": rr, "SW": sw}
+
+
+def make(*args):
+    """`make <args>` under an exclusive lock: the test modules build shared artefacts (tests/emu libraries, tests/cpp programs) from
+    their fixtures, and under pytest-xdist several workers reach those fixtures at once -- two makes rebuilding the same library is how
+    a worker ends up loading a half-written .so.  Serialised, the second make finds its targets up to date."""
+    import fcntl
+    import subprocess
+    os.makedirs(os.path.join(ROOT, "tests", "cpp", "_build_emu"), exist_ok=True)
+    with open(os.path.join(ROOT, "tests", "cpp", "_build_emu", ".make.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return subprocess.run(["make", *map(str, args)], check=True, capture_output=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)

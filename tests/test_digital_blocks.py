@@ -14,7 +14,7 @@ import subprocess
 
 import pytest
 
-from parity_common import ROOT
+from parity_common import ROOT, make
 
 CPP = os.path.join(ROOT, "tests", "cpp")
 GOLDEN = os.path.join(ROOT, "tests", "golden", "digital_blocks.json")
@@ -33,8 +33,8 @@ def _compare(exe):
 
 def test_digital_blocks_match_reference_under_host_emulation():
     """CPU: the event queue and the block models (host code) with the kernels emulated (tests/emu, test infrastructure)."""
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu")], check=True, capture_output=True)
-    subprocess.run(["make", "-j8", "-C", CPP, "emu"], check=True, capture_output=True)
+    make("-C", os.path.join(ROOT, "tests", "emu"))
+    make("-j8", "-C", CPP, "emu")
     _compare(os.path.join(CPP, "_build_emu", "digital_blocks"))
 
 
@@ -58,5 +58,5 @@ def test_golden_covers_every_state_of_every_block():
 
 @pytest.mark.gpu
 def test_digital_blocks_match_reference():
-    subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
+    make("-C", CPP)
     _compare(os.path.join(CPP, "_build", "digital_blocks"))

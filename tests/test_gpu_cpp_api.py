@@ -17,7 +17,7 @@ import subprocess
 
 import pytest
 
-from parity_common import ROOT
+from parity_common import ROOT, make
 
 CPP = os.path.join(ROOT, "tests", "cpp")
 TESTS = ["known_answers", "user_model_overlay", "overlay_batch", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
@@ -25,14 +25,14 @@ TESTS = ["known_answers", "user_model_overlay", "overlay_batch", "bridge_tr", "d
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.run(["make", "-C", CPP], check=True, capture_output=True)
+    make("-C", CPP)
     return os.path.join(CPP, "_build")
 
 
 @pytest.fixture(scope="module")
 def built_emu():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu")], check=True, capture_output=True)
-    subprocess.run(["make", "-j8", "-C", CPP, "emu"], check=True, capture_output=True)
+    make("-C", os.path.join(ROOT, "tests", "emu"))
+    make("-j8", "-C", CPP, "emu")
     return os.path.join(CPP, "_build_emu")
 
 

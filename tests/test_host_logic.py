@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from parity_common import ROOT, golden
+from parity_common import ROOT, golden, make
 
 
 def test_library_exports_every_header_symbol(pe):
@@ -50,7 +50,7 @@ def test_reference_ctypes_client_binds_and_runs(emu_lib):
     drives create_circuit -> circuit_analyze -> circuit_sample on the known answer of test/0008.dll/dll_main_smoke.cpp
     (VDC 5 V across 1 kOhm: 5 V, 5 mA), and gets a loud refusal from an out-of-scope entry point."""
     emu_dir = os.path.dirname(emu_lib)
-    subprocess.run(["make", "-C", emu_dir, "libphyengine_emu.so"], check=True, capture_output=True)
+    make("-C", emu_dir, "libphyengine_emu.so")
     product = os.path.join(ROOT, "phy-engine_amd", "libpe_hip.so")
     code = f"""
 import ctypes as ct, os, sys
@@ -176,7 +176,7 @@ def test_mesh_deck_matches_survey_counts(pe):
 @pytest.fixture(scope="module")
 def emu_lib():
     emu = os.path.join(ROOT, "tests", "emu")
-    subprocess.run(["make", "-C", emu], check=True, capture_output=True)
+    make("-C", emu)
     return os.path.join(emu, "libpe_hip_emu.so")
 
 

@@ -18,7 +18,7 @@ import subprocess
 
 import pytest
 
-from parity_common import ROOT
+from parity_common import ROOT, make
 
 CPP = os.path.join(ROOT, "tests", "cpp")
 GOLD = os.path.join(ROOT, "tests", "golden", "penl")
@@ -29,8 +29,8 @@ needs_ref = pytest.mark.skipif(not (os.path.exists(REF) and os.path.exists(REF_K
 
 @pytest.fixture(scope="module")
 def tool():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu")], check=True, capture_output=True)
-    subprocess.run(["make", "-C", CPP, "_build_emu/penl_tool"], check=True, capture_output=True)
+    make("-C", os.path.join(ROOT, "tests", "emu"))
+    make("-C", CPP, "_build_emu/penl_tool")
     return os.path.join(CPP, "_build_emu", "penl_tool")
 
 
@@ -266,7 +266,7 @@ def test_real_leveldb_opens_the_directories_this_build_writes(tool, tmp_path):
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.fixture(scope="module")
 def gpu_tool():
-    subprocess.run(["make", "-C", CPP, "_build/penl_tool"], check=True, capture_output=True)
+    make("-C", CPP, "_build/penl_tool")
     return os.path.join(CPP, "_build", "penl_tool")
 
 

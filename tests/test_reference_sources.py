@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import pytest
 
-from parity_common import ROOT
+from parity_common import ROOT, make
 
 REF_TESTS = "/root/reference/test"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF_TESTS), reason="the reference tree only exists in the build container")
@@ -50,7 +50,7 @@ def _programs():
 
 @pytest.fixture(scope="module")
 def built():
-    subprocess.run(["make", "-C", EMU], check=True, capture_output=True)
+    make("-C", EMU)
     os.makedirs(OUT, exist_ok=True)
     # the BSIM3 model header includes "../../model_refs/base.h" and "PN_junction.h" relative to ITSELF: map those two paths to this
     # repository's forwarding headers (the plug-in API and the junction model the header is compiled against)

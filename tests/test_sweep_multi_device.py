@@ -8,13 +8,15 @@ import sys
 import numpy as np
 import pytest
 
+from parity_common import make
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "emu", "libpe_hip_emu.so")
 
 
 @pytest.fixture(scope="module")
 def emu():
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu")], check=True, capture_output=True)
+    make("-C", os.path.join(ROOT, "tests", "emu"))
     return EMU
 
 
