@@ -223,7 +223,12 @@ namespace pe_eng PE_ENG_HIDDEN
             }
             // (the wave-front class keeps the geometry above: wave fronts that do not qualify for the lane-group kernel -- order 33..45, or
             //  above one -- stay with the per-instance wave phase, which is cheaper for them than the cooperative phase)
-            so.quad_mid = env_int("PHY_ENGINE_HIP_MID", 0) != 0 ? 1 : 0;  // measured slower than the cooperative phase (pe_quad.hpp): off
+            // The MID launch (order 33..64 on the lane-group scheme, pe_quad.hpp) measured slower than the cooperative phase and is no
+            // longer selectable: since the hybrid wave phase a MID front may sit above a per-instance wave front, which the parts kernel
+            // factors AFTER the MID launch -- the MID front then assembles last iteration's update matrix (Newton still converges, one
+            // iteration later: seen as 3.14 instead of 2.48 iterations per step on M10k).  Re-measured on the round's final tree before
+            // retiring it (scripts/r3_mid.sh): it takes 0.69 ms out of k_m2_factor_parts and costs 1.95 ms.  PHY_ENGINE_HIP_MID is ignored.
+            so.quad_mid = 0;
             // update matrices whose parent follows in the same list could stay on an LDS stack: 8 wavefronts per CU (two per SIMD at this
             // kernel's register count) share the 160 KB -> 600 doubles per instance of a quad
             // (measured slower than the arena for the fronts it applies to, pe_quad.hpp PE_QUAD_LDS_STACK: off unless asked for)
