@@ -124,8 +124,10 @@ namespace pe
         int const *wave_ptr, *wave_list, *coop_ptr, *coop_list, *top_ptr, *top_list;
         int n_parts, n_top_levels, n_waves;
         int top_cnt[64];        // fronts per top level (host-side copy for the launch geometry)
-        int top_wide[64]{};     // 1: the level runs one 16-wavefront workgroup per front with a CU's whole LDS (k_m2_factor_top_wide)
-        int lds_top_doubles{};  // dynamic LDS of those launches, in doubles (>= lds_doubles)
+        int top_wide[64]{};     // 1 / 2: the level runs one 16-wavefront workgroup per front with a CU's whole LDS (k_m2_factor_top_wide; 2: it holds
+                                // fronts formed against that LDS); 3: one 8-wavefront workgroup per front with half a CU's LDS (k_m2_factor_top_mid)
+        int lds_top_doubles{};  // dynamic LDS of the 16-wavefront launches, in doubles (>= lds_doubles)
+        int lds_mid_doubles{};  // ... of the 8-wavefront launches of the levels marked 3
         int* active;            // [.] multi-workgroup mode: instances still iterating
         int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)
@@ -136,6 +138,8 @@ namespace pe
         int lds_bstack_off{};   // the backward pass keeps the solved vectors of a wave front's ancestors inside the subtree on a stack:
         int const *f_wstack{}, *f_wpar{};  //   offsets of a wave front's vector and of its parent's (-1: root of the subtree)
         int lds_wave_stage{}, lds_coop_stage{};  // doubles of the staged block of a wavefront / of the workgroup in the triangular solves
+        int lds_top_stage{};                     // ... of the workgroup in the triangular solves of the TOP fronts (>= lds_coop_stage: their pivot limit may be larger)
+        int lds_solve_top_doubles{};             // dynamic LDS of k_m2_solve_top, in doubles
         int lds_doubles;        // dynamic LDS size of a launch, in doubles
         int lds_solve_doubles;  // ... of the triangular-solve kernels of the split schedule
         // lean plan of the backward pass (front_backward_lean: only U11 staged): slot, stack offset, staged block, launch size

@@ -30,6 +30,16 @@ namespace pe_eng PE_ENG_HIDDEN
     }
 
 
+    // LDS panel need of a front in the panel layout (pe_front.hpp: L panel m x p + U panel p x u, odd leading dimensions)
+    long long panel_need(int p, int u) { return static_cast<long long>(pe::pe_ld(p + u)) * p + static_cast<long long>(pe::pe_ld(p)) * u; }
+    // a front the ordinary launches cannot take: more pivots than their staged blocks hold, or panels beyond their LDS share
+    // (0: they can; 3: it fits half a CU's LDS -- the 8-wavefront launch; 2: it needs the 16-wavefront launch with a CU's whole LDS)
+    int lds_class(pe::Symbolic const& S, pe::SymbolicOptions const& so, int s)
+    {
+        if(S.f_kind[s] == 0 || (S.f_p[s] <= so.max_pivots && panel_need(S.f_p[s], S.f_u[s]) <= so.panel_doubles)) return 0;
+        return (so.panel_doubles_mid > 0 && panel_need(S.f_p[s], S.f_u[s]) <= so.panel_doubles_mid) ? 3 : 2;
+    }
+
     int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
     {
         V.nfronts = S.nfronts;
@@ -76,6 +86,11 @@ namespace pe_eng PE_ENG_HIDDEN
         V.lds_slot = so.wave_slot > 0 ? static_cast<int>(so.wave_slot) : (pe::pe_ld(so.wave_m) + 1) * so.wave_m;
         V.lds_wave_stage = so.wave_m * so.wave_p;              // a wavefront stages the whole m x p panel of its (small) fronts
         V.lds_coop_stage = std::max(V.max_p * V.max_p, std::min(64, V.max_m) * V.max_p);
+        // (top fronts regrouped against a CU's LDS may carry more pivots than the fronts of the parts: regroup_wide_top)
+        int max_p_top = V.max_p;
+        for(int s = 0; s < S.nfronts; ++s)
+            if(S.f_kind[s] == 2) max_p_top = std::max(max_p_top, S.f_p[s]);
+        V.lds_top_stage = std::max(max_p_top * max_p_top, std::min(64, V.max_m) * max_p_top);
         V.lds_bstack_off = so.wave_m + V.lds_wave_stage + 64;  // t[m] + staged block + partial sums of one wavefront,
         V.lds_sslot = V.lds_bstack_off + std::max(1, S.wave_stack);  // + the backward stack (the solved vectors along one path of a wave subtree)
         V.lds_wave_stage_b = so.wave_p * so.wave_p;            // backward pass: U11 only (front_backward_lean)
@@ -93,6 +108,7 @@ namespace pe_eng PE_ENG_HIDDEN
             V.lds_solve_doubles = static_cast<int>(need_solve + 2);
             V.lds_solve_b_doubles = static_cast<int>(std::max(static_cast<long long>(so.n_waves) * V.lds_sslot_b,
                                                               static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64) + 2);
+            V.lds_solve_top_doubles = static_cast<int>(std::max<long long>(need_solve, static_cast<long long>(V.max_m) + V.lds_top_stage + so.n_waves * 64) + 2);
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
@@ -105,8 +121,19 @@ namespace pe_eng PE_ENG_HIDDEN
             bool const chain_lds = knob(h, "TOP_CHAIN_LDS", 1) != 0;  // developer knob: 0 = round 2's layout of the top fronts
             long long const whole_cu = h->lds_limit / 8 - 160 - 8;
             for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * batch <= 320)) ? 1 : 0;
+            // levels that hold a front formed against a CU's whole LDS (regroup_wide_top): wide whatever their population, 2 = every
+            // front of the level is laid out against the larger cap
+            // ... 3 = fronts formed against half a CU's LDS at a level that is not wide by its population: the 8-wavefront launch
+            V.lds_mid_doubles = static_cast<int>(std::max<long long>(V.lds_doubles, (h->lds_limit / 8 - 160) / 2 - 8));
+            for(int l = 0; l < V.n_top_levels; ++l)
+            {
+                int need = 0;
+                for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k)
+                    if(int const c = lds_class(S, so, S.top_list[k]); c != 0) need = (need == 2 || c == 2) ? 2 : 3;
+                if(need != 0) V.top_wide[l] = (need == 2 || V.top_wide[l] != 0) ? 2 : 3;
+            }
             V.lds_top_doubles = chain_lds ? static_cast<int>(std::max<long long>(V.lds_doubles, whole_cu)) : V.lds_doubles;
-            if(!pe::build_assembly_lists(S, V.lds_slot, V.lds_doubles - 2, chain_lds ? V.top_wide : nullptr, V.lds_top_doubles - 2))
+            if(!pe::build_assembly_lists(S, V.lds_slot, V.lds_doubles - 2, chain_lds ? V.top_wide : nullptr, V.lds_top_doubles - 2, V.lds_mid_doubles - 2))
                 return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
         }
         HIPCHK(h, pool.upload(V.f_mode, S.f_mode));
@@ -266,6 +293,64 @@ namespace pe_eng PE_ENG_HIDDEN
         return so;
     }
 
+    // Second pass of the analysis for the split schedule: the top levels that run one 16-wavefront workgroup per front anyway (one
+    // workgroup per CU: k_m2_factor_top_wide -- every top level of a single circuit, the levels with fronts x instances <= CUs + 25 %
+    // of a sweep) were cut into links that fit the ORDINARY workgroup's LDS share and pivot limit: at 128 instances the root
+    // separator of the 10k mesh and its two children are eleven levels of links with 3..32 pivots and orders 86..150, each link a
+    // front's fixed work and a trip of its Schur block through HBM.  With the unknowns of those levels marked, the analysis forms
+    // their fronts against a CU's whole LDS and 64 pivots, in links of equal length; the factorisation is the same elimination in
+    // fewer, larger steps.  Levels of up to 1 280 workgroups get HALF a CU's LDS the same way (the 8-wavefront launch
+    // k_m2_factor_top_mid, two workgroups per CU).  Kept only if every such front ends up at a top level (those levels are then forced
+    // onto the launch that has the LDS, upload_symbolic: V.top_wide 2 / 3); otherwise the first pass stands.  Knob TOP_BIG=0: first
+    // pass only.  Measured on M10k (profiles/r03_ab_runs.log ab16-ab20): 1.594 -> 1.412 ms per Newton iteration at 128 instances,
+    // 2.591 -> 2.354 at 256, 4.62 -> 4.52 at 512, 0.516 -> 0.480 for the single circuit; 1 024 instances within the noise (-0.4 %).
+    void regroup_wide_top(pe_hip_engine* h, int batch, int geometry_rows, int n, int const* rp, int const* ci, double const* vals, pe::Symbolic& S,
+                          pe::SymbolicOptions& so)
+    {
+        so.big_unknowns = nullptr;
+        bool const split = geometry_rows >= 3000 && knob(h, "SPLIT", -1) != 0 && S.n_parts > 1;
+        if(!split || knob(h, "TOP_BIG", 1) == 0 || knob(h, "WIDE_TOP", 1) == 0 || knob(h, "TOP_CHAIN_LDS", 1) == 0) return;
+        int const gb = geometry_batch(h, batch), levels = static_cast<int>(S.top_ptr.size()) - 1;
+        std::vector<char> big(static_cast<size_t>(n), 0);
+        int marked = 0;
+        bool const half_knob = knob(h, "TOP_BIG", 1) != 2;  // developer knob: 2 = whole-CU levels only
+        // (half-CU levels: up to 1 280 workgroups -- 2.5 rounds of the 512 that fit; measured against 640, profiles/r03_ab_runs.log ab20:
+        //  1.412 / 1.456 ms per iteration at 128 instances, 2.354 / 2.504 at 256, 4.52 / 4.56 at 512, 8.58 / 8.61 at 1 024)
+        long long const half_wgs = std::max(0, knob(h, "TOP_HALF_WGS", 1280));
+        for(int l = 0; l < levels; ++l)
+        {
+            long long const wgs = static_cast<long long>(S.top_ptr[l + 1] - S.top_ptr[l]) * gb;
+            // whole CU: the rule of V.top_wide; half a CU: the 8-wavefront launch, two workgroups per CU
+            int const cls = (!so.shared_cu || wgs <= 320) ? 1 : ((half_knob && wgs <= half_wgs) ? 2 : 0);
+            if(cls == 0) continue;
+            for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k)
+            {
+                int const s = S.top_list[k];
+                for(int c = S.f_col0[s]; c < S.f_col0[s] + S.f_p[s]; ++c) big[static_cast<size_t>(S.col_src[c])] = static_cast<char>(cls);
+                ++marked;
+            }
+        }
+        if(marked < 2) return;  // (nothing to merge)
+        pe::SymbolicOptions so2 = so;
+        so2.big_unknowns = &big;
+        // (64 = one pivot per lane of the triangular solves is the hard limit; measured on M10k, profiles/r03_ab_runs.log ab18: 64 against 48
+        //  is 1.465 / 1.484 ms per iteration at 128 instances, 0.480 / 0.519 for the single circuit, equal at 256)
+        so2.max_pivots_top = std::clamp(knob(h, "TOP_MAX_PIVOTS", 64), 1, 64);
+        long long const whole_cu = h->lds_limit / 8 - 160 - 8;
+        long long const behind = std::max<long long>(so.panel_reserve, S.max_m + 8 + 512);  // (right-hand-side column + staged child maps)
+        so2.panel_doubles_top = whole_cu - 2 - behind;
+        so2.panel_doubles_mid = so.shared_cu ? (h->lds_limit / 8 - 160) / 2 - 8 - 2 - behind : 0;
+        pe::Symbolic S2;
+        if(!pe::analyze(n, rp, ci, vals, so2, S2)) return;
+        if(static_cast<int>(S2.top_ptr.size()) - 1 > 64 || S2.max_m + 8 > so.panel_reserve || S2.n_parts != S.n_parts) return;
+        for(int s = 0; s < S2.nfronts; ++s)
+            if(lds_class(S2, so2, s) != 0 && S2.f_kind[s] != 2) return;  // a front of a part would need a CU's LDS: keep the first pass
+        S = std::move(S2);
+        so.max_pivots_top = so2.max_pivots_top;
+        so.panel_doubles_top = so2.panel_doubles_top;
+        so.panel_doubles_mid = so2.panel_doubles_mid;
+    }
+
     // Symbolic analysis + the LDS-fit escalation every caller needs (resident circuit AND the solve_csr_real seam): a front's
     // right-hand-side column (m doubles) must fit the reserve behind its panels, and the top of the tree the launch table.
     // (1) a larger reserve; (2) the whole LDS of a CU for one workgroup; else give up loudly.  `geometry_rows`: row count the
@@ -280,7 +365,11 @@ namespace pe_eng PE_ENG_HIDDEN
                 return fail(h, S.structurally_singular ? PE_HIP_ERR_SINGULAR : PE_HIP_ERR_INTERNAL, "symbolic analysis: " + S.error);
             bool const too_deep = static_cast<int>(S.top_ptr.size()) - 1 > 64;
             bool const fits = S.max_m + 8 <= so.panel_reserve;
-            if(fits && !too_deep) return PE_HIP_OK;
+            if(fits && !too_deep)
+            {
+                regroup_wide_top(h, batch, geometry_rows, n, rp, ci, vals, S, so);
+                return PE_HIP_OK;
+            }
             if(attempt == 2) return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: a front of order " + std::to_string(S.max_m) + " does not fit the LDS of a CU");
             so = symbolic_options(h, batch, geometry_rows, std::max(384, S.max_m + 72), attempt == 1 ? 1 : 0);
             if(too_deep) so.n_parts = 1;

@@ -721,7 +721,8 @@ namespace pe
         for(int l = level; l < level + nlev; ++l)
         {
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            // (a level marked 3 holds fronts formed against half a CU's LDS: two of these workgroups per CU)
+            if(!front_factor(tm, V, b, s, pe_lds, (V.top_wide[l] == 3 ? V.lds_mid_doubles : V.lds_doubles) - 2, 0, true))
             {
                 if(tm.tid() == 0) atomicOr(V.flags + b, 4);
                 return;
@@ -771,9 +772,9 @@ namespace pe
         {
             int const l = backward ? level + nlev - 1 - i : level + i;
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
+            if(backward) front_backward(tm, V, b, s, pe_lds, V.max_m, V.lds_top_stage);
             else
-                front_forward(tm, V, b, s, pe_lds, V.max_m, V.lds_coop_stage);
+                front_forward(tm, V, b, s, pe_lds, V.max_m, V.lds_top_stage);
         }
     }
 
@@ -1090,13 +1091,14 @@ namespace pe
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
+        size_t const lds_st = static_cast<size_t>(V.lds_solve_top_doubles) * sizeof(double);  // (top fronts may carry more pivots: larger staged block)
         {
             hipError_t e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_parts<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top<MINW>), lds);
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_wide), static_cast<size_t>(V.lds_top_doubles) * sizeof(double));
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_mid), lds);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_top_mid), std::max(lds, static_cast<size_t>(V.lds_mid_doubles) * sizeof(double)));
             if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_parts<MINW>), lds_s);
-            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_s);
+            if(e == hipSuccess) e = set_lds(reinterpret_cast<void const*>(&k_m2_solve_top<MINW>), lds_st);
             if(e != hipSuccess) return e;
         }
         int const B = V.batch, T = V.n_waves * 64;
@@ -1146,12 +1148,13 @@ namespace pe
             {
                 // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
                 // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %)
-                bool const wide = V.top_wide[l] != 0;  // (the rule lives in upload_symbolic: the fronts' LDS layout depends on it)
+                bool const half = V.top_wide[l] == 3;  // (the rule lives in upload_symbolic: the fronts' LDS layout depends on it)
+                bool const wide = V.top_wide[l] != 0 && !half;
                 static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
-                bool const mid = !wide && MINW == 4 && T == 256 && V.top_cnt[l] * B <= mid_knob;
+                bool const mid = half || (!wide && MINW == 4 && T == 256 && V.top_cnt[l] * B <= mid_knob);
                 if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), static_cast<size_t>(V.lds_top_doubles) * sizeof(double), st, V, l, run(l));
                 else if(mid)
-                    hipLaunchKernelGGL(k_m2_factor_top_mid, dim3(V.top_cnt[l], B), dim3(512), lds, st, V, l, run(l));
+                    hipLaunchKernelGGL(k_m2_factor_top_mid, dim3(V.top_cnt[l], B), dim3(512), half ? static_cast<size_t>(V.lds_mid_doubles) * sizeof(double) : lds, st, V, l, run(l));
                 else
                     hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
             }
@@ -1159,12 +1162,12 @@ namespace pe
         else
         {
             hipLaunchKernelGGL(k_m2_solve_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds_s, st, V, 0);
-            for(int l = 0; l < V.n_top_levels; l += run(l)) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l, run(l), 0);
+            for(int l = 0; l < V.n_top_levels; l += run(l)) hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_st, st, V, l, run(l), 0);
         }
         for(int l = V.n_top_levels - 1; l >= 0;)
         {
             int const n = run_down(l);
-            hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_s, st, V, l - n + 1, n, 1);
+            hipLaunchKernelGGL(k_m2_solve_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds_st, st, V, l - n + 1, n, 1);
             l -= n;
         }
         if(!do_factor && ev0) (void)hipEventRecord(ev0, st);

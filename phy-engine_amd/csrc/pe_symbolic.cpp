@@ -460,6 +460,22 @@ namespace pe
         };
         std::vector<SN> sn;
         auto u_of = [&](SN const& s) { return static_cast<int>(st[s.c1 - 1].size()); };
+        // (second pass: columns whose fronts own a CU's LDS -- SymbolicOptions::big_unknowns; q maps a column to its unknown)
+        bool const has_big = opt.big_unknowns && static_cast<int>(opt.big_unknowns->size()) == n && opt.panel_doubles_top > 0;
+        auto big_class = [&](int c0, int c1)  // 0: ordinary, 1: a CU's whole LDS, 2: half of it
+        {
+            if(!has_big) return 0;
+            int cls = 1;
+            for(int c = c0; c < c1; ++c)
+            {
+                int const k = (*opt.big_unknowns)[q[c]];
+                if(k == 0) return 0;
+                cls = std::max(cls, k);
+            }
+            return cls;
+        };
+        auto big_run = [&](int c0, int c1) { return big_class(c0, c1) != 0; };
+        auto pivots_max = [&](int c0, int c1) { return big_run(c0, c1) ? std::max(opt.max_pivots, opt.max_pivots_top) : opt.max_pivots; };
         auto try_merge = [&](SN& P)
         {
             while(!sn.empty())
@@ -471,7 +487,7 @@ namespace pe
                 int const pC = C.c1 - C.c0, uC = u_of(C);
                 int const pP = P.c1 - P.c0, mP = pP + u_of(P);
                 int const np = pC + pP;
-                if(np > opt.max_pivots) break;
+                if(np > pivots_max(C.c0, P.c1)) break;
                 long long const z = C.zeros + P.zeros + static_cast<long long>(pC) * (mP - uC);
                 double const panel = static_cast<double>(np) * (np + u_of(P)) - 0.5 * np * (np - 1);
                 if(np > opt.relax_small && static_cast<double>(z) > opt.relax_zero_frac * panel) break;
@@ -485,7 +501,7 @@ namespace pe
             while(j < n)
             {
                 SN P{j, j + 1, 0};
-                while(P.c1 < n && parent[P.c1 - 1] == P.c1 && st[P.c1 - 1].size() == st[P.c1].size() + 1 && (P.c1 - P.c0) < opt.max_pivots) ++P.c1;
+                while(P.c1 < n && parent[P.c1 - 1] == P.c1 && st[P.c1 - 1].size() == st[P.c1].size() + 1 && (big_run(P.c0, P.c1 + 1) || (P.c1 - P.c0) < opt.max_pivots)) ++P.c1;  // (second pass: a fundamental run of the top stays ONE group, cut into equal links below)
                 j = P.c1;
                 try_merge(P);
                 sn.push_back(P);
@@ -590,16 +606,19 @@ namespace pe
                 int const rest = c1 - a;
                 int const mfull = rest + ug;
                 int b;
-                if(mfull <= opt.wave_m) b = a + std::min(rest, opt.wave_p);
+                if(mfull <= opt.wave_m && !big_run(c0, c1)) b = a + std::min(rest, opt.wave_p);  // (a front of the top is never a wave front)
                 else if(opt.quad_mid && mfull <= 64)
                     b = a + std::min(rest, 16);  // a candidate MID front of the lane-group kernels: <= 16 pivots (one row set)
                 else
                 {
+                    int const cls = big_class(c0, c1);  // (second pass: a front of the top that owns a CU's LDS, or half of it)
+                    bool const big = cls != 0;
+                    long long const budget = std::max(opt.panel_doubles, cls == 1 ? opt.panel_doubles_top : (cls == 2 ? opt.panel_doubles_mid : 0));
                     int pbest = 0;
-                    for(int pp = std::min(rest, opt.max_pivots); pp >= 1; --pp)
+                    for(int pp = std::min(rest, big ? std::max(opt.max_pivots, opt.max_pivots_top) : opt.max_pivots); pp >= 1; --pp)
                     {
                         long long const uch = (rest - pp) + ug, mch = pp + uch;
-                        if(static_cast<long long>(pe_ld(static_cast<int>(mch))) * pp + static_cast<long long>(pe_ld(pp)) * uch <= opt.panel_doubles)
+                        if(static_cast<long long>(pe_ld(static_cast<int>(mch))) * pp + static_cast<long long>(pe_ld(pp)) * uch <= budget)
                         {
                             pbest = pp;
                             break;
@@ -610,6 +629,9 @@ namespace pe
                         S.error = "front too large for the LDS panels";
                         return false;
                     }
+                    // (links of equal length instead of full ones + a remnant of two or three pivots: the panel need grows with the
+                    //  pivots of a link, so the shorter link fits where the longest did)
+                    if(big) pbest = (rest + (rest + pbest - 1) / pbest - 1) / ((rest + pbest - 1) / pbest);
                     b = a + pbest;
                 }
                 fr.push_back({a, b, c1});
@@ -1249,7 +1271,7 @@ namespace pe
         build_quad_program(S, mlists, 0, S.q2_prog, S.q2_lists, S.q2_lane);
     }
 
-    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide, long long cap_top)
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide, long long cap_top, long long cap_mid)
     {
         int const nf = S.nfronts;
         S.f_mode.assign(nf, 0);
@@ -1261,8 +1283,14 @@ namespace pe
             for(size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
                 // (single-front levels only: measured at 128 instances, the levels with two fronts run 3..5 us SLOWER in the whole-front
                 //  layout of the larger cap -- 27 -> 30, 31 -> 36 us -- while the run of single-front levels gains 12 us, 178 -> 166)
-                if(top_wide[l] && S.top_ptr[l + 1] - S.top_ptr[l] == 1)
+                //  (top_wide 2: a level with fronts formed against the larger cap -- every front of it is laid out against that cap)
+                if(top_wide[l] == 2 || (top_wide[l] == 1 && S.top_ptr[l + 1] - S.top_ptr[l] == 1))
                     for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) wide_level[S.top_list[k]] = static_cast<int>(l);
+        std::vector<char> mid_level(nf, 0);  // a top front at a level of the 8-wavefront launch with half a CU's LDS (top_wide 3)
+        if(top_wide && cap_mid > 0)
+            for(size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
+                if(top_wide[l] == 3)
+                    for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) mid_level[S.top_list[k]] = 1;
         S.gl_ptr.assign(nf + 1, 0);
         S.gl_rptr.assign(nf + 1, 0);
         S.gl_sptr.assign(nf + 1, 0);
@@ -1279,7 +1307,7 @@ namespace pe
         for(int s = 0; s < nf; ++s)
         {
             long long const p = S.f_p[s], u = S.f_u[s], m = p + u;
-            long long const cap = S.f_kind[s] == 0 ? cap_wave : (wide_level[s] >= 0 ? std::max(cap_team, cap_top) : cap_team);
+            long long const cap = S.f_kind[s] == 0 ? cap_wave : (wide_level[s] >= 0 ? std::max(cap_team, cap_top) : (mid_level[s] ? std::max(cap_team, cap_mid) : cap_team));
             int const ch0 = S.f_child_ptr[s], ch1 = S.f_child_ptr[s + 1];
             long long const ldl = pe_ld(static_cast<int>(m)), ldp = pe_ld(static_cast<int>(p));  // odd LDS leading dimensions (pe_device.hpp)
             bool const full = ldl * m + m <= cap;

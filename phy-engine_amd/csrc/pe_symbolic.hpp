@@ -42,6 +42,17 @@ namespace pe
                                          // the symbolic analysis then also builds the quad plan below and pads the arena with a zero region
         int quad_mid{};                  // 1: fronts of order 33..64 whose subtree qualifies form the MID class (f_kind 3) of a second lane-group launch
         int quad_lds_doubles{};          // LDS doubles per instance of a wavefront's update-matrix stack (0: every update matrix goes through the arena)
+        // Second pass of the analysis (pe_engine_policy.cpp analyze_fitting): unknowns whose fronts sat at top levels that run ONE workgroup
+        // per CU anyway (k_m2_factor_top_wide).  Those fronts own a CU's LDS: supernodes made of such unknowns only may take
+        // max_pivots_top pivots and are split against panel_doubles_top, in links of equal length -- a separator of the top then is one
+        // or two fronts instead of a chain of LDS-sized links, each of which costs a front's fixed work and a trip of its Schur block
+        // through HBM.  Null: every front obeys max_pivots / panel_doubles.
+        // Entry 1: a CU's whole LDS (panel_doubles_top); 2: half of it (panel_doubles_mid: levels that run two 8-wavefront workgroups
+        // per CU, k_m2_factor_top_mid); a supernode takes the smallest share among its unknowns.
+        std::vector<char> const* big_unknowns{nullptr};
+        int max_pivots_top{64};
+        long long panel_doubles_top{0};
+        long long panel_doubles_mid{0};
     long long panel_reserve{384};    // LDS doubles kept free behind the panels of a large front (right-hand-side column, staged child maps)
     long long panel_doubles{18000};  // LDS doubles available for the L (m x p) and U (p x u) panels of a cooperative front
     };
@@ -164,6 +175,7 @@ namespace pe
 
     // cap_wave / cap_team: LDS doubles of a wavefront's slot / of the whole workgroup (the `cap` front_factor is called with).
     // Returns false (S.error set) when an offset does not fit its index type.
-    // `top_wide` (may be null): per top LEVEL, 1 = one workgroup per front with `cap_top` doubles of LDS (the 16-wavefront launch)
-    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide = nullptr, long long cap_top = 0);
+    // `top_wide` (may be null): per top LEVEL, 1 = one workgroup per front with `cap_top` doubles of LDS (the 16-wavefront launch),
+    // 2 = the same and every front of the level laid out against cap_top, 3 = the 8-wavefront launch with `cap_mid` doubles
+    bool build_assembly_lists(Symbolic& S, long long cap_wave, long long cap_team, int const* top_wide = nullptr, long long cap_top = 0, long long cap_mid = 0);
 }  // namespace pe

@@ -255,17 +255,17 @@ namespace pe
                 ChainState cs;  // (a run of single-front wide levels is ONE workgroup on the device: k_m2_factor_top_wide)
                 for(int l = 0; l < V.n_top_levels; ++l)
                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles) - 2, 0, true, V.top_wide[l] ? &cs : nullptr))
+                        if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] == 3 ? V.lds_mid_doubles : (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles)) - 2, 0, true, (V.top_wide[l] && V.top_wide[l] != 3) ? &cs : nullptr))
                             V.flags[b] |= 4;
             }
             else
             {
                 for(int q = 0; q < V.n_parts; ++q) forward_part(tm, V, b, q, mem.data());
                 for(int l = 0; l < V.n_top_levels; ++l)
-                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_forward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_top_stage);
             }
             for(int l = V.n_top_levels - 1; l >= 0; --l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_top_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
         }
         emu_backward_quads(V);  // (its own launch on the device, behind the parts' backward pass)
@@ -334,10 +334,10 @@ namespace pe
             ChainState cs;
             for(int l = 0; l < V.n_top_levels; ++l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                    if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles) - 2, 0, true, V.top_wide[l] ? &cs : nullptr))
+                    if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] == 3 ? V.lds_mid_doubles : (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles)) - 2, 0, true, (V.top_wide[l] && V.top_wide[l] != 3) ? &cs : nullptr))
                         V.flags[b] |= 4;
             for(int l = V.n_top_levels - 1; l >= 0; --l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_coop_stage);
+                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_top_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());
         }
         emu_backward_quads(V);
