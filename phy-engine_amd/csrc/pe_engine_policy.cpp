@@ -120,7 +120,10 @@ namespace pe_eng PE_ENG_HIDDEN
             bool const wide_knob = knob(h, "WIDE_TOP", 1) != 0;
             bool const chain_lds = knob(h, "TOP_CHAIN_LDS", 1) != 0;  // developer knob: 0 = round 2's layout of the top fronts
             long long const whole_cu = h->lds_limit / 8 - 160 - 8;
-            for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * batch <= 320)) ? 1 : 0;
+            // (the population rule counts the instances the GEOMETRY was chosen for -- knob GEOMETRY_BATCH: the host emulation runs the
+            //  launch plan of a large sweep on one instance, tests/test_host_logic.py)
+            int const gbatch = geometry_batch(h, batch);
+            for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * gbatch <= 320)) ? 1 : 0;
             // levels that hold a front formed against a CU's whole LDS (regroup_wide_top): wide whatever their population, 2 = every
             // front of the level is laid out against the larger cap
             // ... 3 = fronts formed against half a CU's LDS at a level that is not wide by its population: the 8-wavefront launch

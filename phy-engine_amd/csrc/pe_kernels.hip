@@ -22,6 +22,7 @@
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
 #include "pe_quad.hpp"
+#include "pe_top_plan.hpp"
 
 namespace pe
 {
@@ -1104,13 +1105,9 @@ namespace pe
         int const B = V.batch, T = V.n_waves * 64;
         int const G = grid_per_instance(V);
         // runs of single-front top levels share a launch
-        auto run = [&](int l)
-        {
-            int n = 1;
-            if(V.top_cnt[l] == 1)
-                while(l + n < V.n_top_levels && V.top_cnt[l + n] == 1) ++n;
-            return n;
-        };
+        // (... of the same launch class: a level whose fronts were formed against a CU's whole / half LDS must run on the launch that
+        //  has that LDS -- pe_top_plan.hpp)
+        auto run = [&](int l) { return top_run(V, l); };
         auto run_down = [&](int l)
         {
             int n = 1;
@@ -1144,20 +1141,21 @@ namespace pe
             }
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);
-            for(int l = 0; l < V.n_top_levels; l += run(l))
-            {
-                // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
-                // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %)
-                bool const half = V.top_wide[l] == 3;  // (the rule lives in upload_symbolic: the fronts' LDS layout depends on it)
-                bool const wide = V.top_wide[l] != 0 && !half;
-                static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
-                bool const mid = half || (!wide && MINW == 4 && T == 256 && V.top_cnt[l] * B <= mid_knob);
-                if(wide) hipLaunchKernelGGL(k_m2_factor_top_wide, dim3(V.top_cnt[l], B), dim3(1024), static_cast<size_t>(V.lds_top_doubles) * sizeof(double), st, V, l, run(l));
-                else if(mid)
-                    hipLaunchKernelGGL(k_m2_factor_top_mid, dim3(V.top_cnt[l], B), dim3(512), half ? static_cast<size_t>(V.lds_mid_doubles) * sizeof(double) : lds, st, V, l, run(l));
-                else
-                    hipLaunchKernelGGL(k_m2_factor_top<MINW>, dim3(V.top_cnt[l], B), dim3(T), lds, st, V, l, run(l));
-            }
+            // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
+            // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %);
+            // the rule lives in upload_symbolic (the fronts' LDS layout depends on it), the plan in pe_top_plan.hpp
+            static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
+            for_each_top_launch(V, B, MINW == 4 && T == 256, mid_knob,
+                                [&](TopLaunch const& t)
+                                {
+                                    dim3 const grid(V.top_cnt[t.level], B);
+                                    size_t const bytes = static_cast<size_t>(t.lds_doubles) * sizeof(double);
+                                    if(t.kind == 1) hipLaunchKernelGGL(k_m2_factor_top_wide, grid, dim3(1024), bytes, st, V, t.level, t.nlev);
+                                    else if(t.kind != 0)
+                                        hipLaunchKernelGGL(k_m2_factor_top_mid, grid, dim3(512), bytes, st, V, t.level, t.nlev);
+                                    else
+                                        hipLaunchKernelGGL(k_m2_factor_top<MINW>, grid, dim3(T), bytes, st, V, t.level, t.nlev);
+                                });
         }
         else
         {

@@ -9,6 +9,7 @@
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
 #include "pe_quad.hpp"
+#include "pe_top_plan.hpp"
 
 namespace pe
 {
@@ -202,6 +203,23 @@ namespace pe
         }
     };
 
+
+    // The top levels as the device runs them (pe_top_plan.hpp: the same plan as m2_sequence): every level of a launch gets that
+    // launch's LDS -- front_factor asserts that the front fits -- and a 16-wavefront launch carries its ChainState through its run.
+    template <class Team>
+    bool emu_factor_top(Team const& tm, DevView const& V, int b, double* mem)
+    {
+        bool ok = true;
+        for_each_top_launch(V, V.batch, V.high_occupancy && V.n_waves == 4, 512,
+                            [&](TopLaunch const& t)
+                            {
+                                ChainState cs;  // (a run of single-front wide levels is ONE workgroup on the device: k_m2_factor_top_wide)
+                                for(int l = t.level; l < t.level + t.nlev; ++l)
+                                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
+                                        if(!front_factor<Team, true>(tm, V, b, V.top_list[i], mem, static_cast<int>(t.lds_doubles) - 2, 0, true, t.kind == 1 ? &cs : nullptr)) ok = false;
+                            });
+        return ok;
+    }
     hipError_t launch_tr_steps(hipStream_t, DevView const& V, double dt, int nsteps, bool reuse)
     {
         std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
@@ -252,11 +270,7 @@ namespace pe
             {
                 for(int q = 0; q < V.n_parts; ++q)
                     if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
-                ChainState cs;  // (a run of single-front wide levels is ONE workgroup on the device: k_m2_factor_top_wide)
-                for(int l = 0; l < V.n_top_levels; ++l)
-                    for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                        if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] == 3 ? V.lds_mid_doubles : (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles)) - 2, 0, true, (V.top_wide[l] && V.top_wide[l] != 3) ? &cs : nullptr))
-                            V.flags[b] |= 4;
+                if(!emu_factor_top(tm, V, b, mem.data())) V.flags[b] |= 4;
             }
             else
             {
@@ -331,11 +345,7 @@ namespace pe
             double n4[4];
             for(int q = 0; q < V.n_parts; ++q)
                 if(!factor_part(tm, V, b, q, mem.data(), true)) V.flags[b] |= 4;
-            ChainState cs;
-            for(int l = 0; l < V.n_top_levels; ++l)
-                for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
-                    if(!front_factor<decltype(tm), true>(tm, V, b, V.top_list[i], mem.data(), (V.top_wide[l] == 3 ? V.lds_mid_doubles : (V.top_wide[l] ? V.lds_top_doubles : V.lds_doubles)) - 2, 0, true, (V.top_wide[l] && V.top_wide[l] != 3) ? &cs : nullptr))
-                        V.flags[b] |= 4;
+            if(!emu_factor_top(tm, V, b, mem.data())) V.flags[b] |= 4;
             for(int l = V.n_top_levels - 1; l >= 0; --l)
                 for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i) front_backward(tm, V, b, V.top_list[i], mem.data(), V.max_m, V.lds_top_stage);
             for(int q = 0; q < V.n_parts; ++q) backward_part(tm, V, b, q, mem.data());

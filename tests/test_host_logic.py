@@ -317,6 +317,35 @@ assert np.max(np.abs(eng2.solution()[0] - eng.solution()[0]) / (1e-9 + 1e-9 * np
     subprocess.run(["python3", "-c", code], check=True, timeout=900)
 
 
+def test_launch_plan_of_a_sweep_under_host_emulation(emu_lib, oracle_mod):
+    """The top levels of the 10k-node mesh as a sweep of 128 / 512 / 1 024 instances runs them (knob GEOMETRY_BATCH: the geometry, the
+    second analysis pass that forms the top fronts against the LDS of their launch, and the launch plan of pe_top_plan.hpp are those
+    of the large sweep; one instance is computed).  The emulation gives every level of a launch that launch's LDS and asserts that a
+    front fits: a level with half-CU fronts that rode along in a run of ordinary levels overran the LDS on the device
+    (round 3; caught here since the emulation follows the same plan).  Same Newton counts and solution as the oracle."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load(); orc = pe_load.load_oracle()
+deck = pe.deck.rc_mesh(100, 100, 1, True)
+o = orc.Oracle(deck); o.analyze_tr(1e-10, 2)
+levels = {{}}
+for g in (128, 512, 1024):
+    eng = pe.ffi.Engine(); eng.set_knob('GEOMETRY_BATCH', g); eng.set_options(g_min=0.0); eng.load_deck(deck); eng.reset()
+    st = eng.analyze_tr(1e-10, 2)
+    assert st['newton_iters'] == sum(o.newton_iters), (g, st['newton_iters'])
+    assert np.max(np.abs(eng.solution()[0] - o.x) / (1e-6 + 1e-5 * np.abs(o.x))) <= 1.0, g
+    levels[g] = eng.info()['n_top_levels']
+    eng0 = pe.ffi.Engine(); eng0.set_knob('GEOMETRY_BATCH', g); eng0.set_knob('TOP_BIG', 0); eng0.set_options(g_min=0.0); eng0.load_deck(deck); eng0.reset()
+    eng0.analyze_tr(1e-10, 2)
+    assert eng0.info()['n_top_levels'] > levels[g], (g, eng0.info()['n_top_levels'], levels[g])
+    assert np.max(np.abs(eng0.solution()[0] - eng.solution()[0]) / (1e-9 + 1e-9 * np.abs(o.x))) <= 1.0, g
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=900)
+
+
 def test_solver_seam_large_front_under_host_emulation(emu_lib):
     """solve_csr_real with ONE dense front of order 450 and with a 2-D mesh whose top separator exceeds the default LDS
     reserve: the seam runs the same LDS-fit escalation as the resident circuit (round-1 advisor finding: an LDS overrun past
