@@ -171,7 +171,9 @@ namespace pe_eng PE_ENG_HIDDEN
             // for at least one instance inside 4 GiB (else the wave fronts fall back to the per-instance path of factor_part)
             long long const stride = 8 * std::max({static_cast<long long>(S.nnzA), V.factor_doubles, V.arena_doubles, static_cast<long long>(S.n)});
             V.quad = stride < (1ll << 31) ? (knob(h, "QUAD", 1) | 1) : 0;
-            V.quad_back = (V.quad && knob(h, "QUAD_BACK", 1) != 0) ? 1 : 0;  // the same fronts' backward pass on the lane-group kernel
+            // the same fronts' backward pass on the lane-group kernel -- from 192 instances on: at 128 (one of its wavefronts per SIMD) the
+            // per-instance backward pass of the parts is 1.3 % faster per iteration, at 256 they are equal (profiles/r03_ab_runs.log ab22)
+            V.quad_back = (V.quad && knob(h, "QUAD_BACK", geometry_batch(h, batch) >= 192 ? 1 : 0) != 0) ? 1 : 0;
         }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
