@@ -304,7 +304,7 @@ namespace pe_eng PE_ENG_HIDDEN
     // separator of the 10k mesh and its two children are eleven levels of links with 3..32 pivots and orders 86..150, each link a
     // front's fixed work and a trip of its Schur block through HBM.  With the unknowns of those levels marked, the analysis forms
     // their fronts against a CU's whole LDS and 64 pivots, in links of equal length; the factorisation is the same elimination in
-    // fewer, larger steps.  Levels of up to 1 280 workgroups get HALF a CU's LDS the same way (the 8-wavefront launch
+    // fewer, larger steps.  Levels of up to 2 048 workgroups get HALF a CU's LDS the same way (the 8-wavefront launch
     // k_m2_factor_top_mid, two workgroups per CU).  Kept only if every such front ends up at a top level (those levels are then forced
     // onto the launch that has the LDS, upload_symbolic: V.top_wide 2 / 3); otherwise the first pass stands.  Knob TOP_BIG=0: first
     // pass only.  Measured on M10k (profiles/r03_ab_runs.log ab16-ab20): 1.594 -> 1.412 ms per Newton iteration at 128 instances,
@@ -319,9 +319,10 @@ namespace pe_eng PE_ENG_HIDDEN
         std::vector<char> big(static_cast<size_t>(n), 0);
         int marked = 0;
         bool const half_knob = knob(h, "TOP_BIG", 1) != 2;  // developer knob: 2 = whole-CU levels only
-        // (half-CU levels: up to 1 280 workgroups -- 2.5 rounds of the 512 that fit; measured against 640, profiles/r03_ab_runs.log ab20:
-        //  1.412 / 1.456 ms per iteration at 128 instances, 2.354 / 2.504 at 256, 4.52 / 4.56 at 512, 8.58 / 8.61 at 1 024)
-        long long const half_wgs = std::max(0, knob(h, "TOP_HALF_WGS", 1280));
+        // (half-CU levels: up to 2 048 workgroups -- four rounds of the 512 that fit.  Measured, profiles/r03_ab_runs.log: 1 280 against 640
+        //  (ab20) 1.412 / 1.456 ms per iteration at 128 instances, 2.354 / 2.504 at 256, 4.52 / 4.56 at 512; 2 048 against 1 280 (ab23) takes in
+        //  the two-front levels of 1 024 instances: 2.88 / 3.00 ms per iteration outside the dominant launch pair, nothing changes below)
+        long long const half_wgs = std::max(0, knob(h, "TOP_HALF_WGS", 2048));
         for(int l = 0; l < levels; ++l)
         {
             long long const wgs = static_cast<long long>(S.top_ptr[l + 1] - S.top_ptr[l]) * gb;
