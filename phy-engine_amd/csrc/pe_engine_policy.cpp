@@ -231,7 +231,9 @@ namespace pe_eng PE_ENG_HIDDEN
         {
             // (re-swept after the larger wave-front class: 128 instances 16 parts 1.65 ms per iteration against 1.68 with 8 and 1.77 with 12;
             //  256 instances 8 parts 2.74 against 2.81 with 4; 512 and 1 024 instances stay at 4)
-            so.n_parts = batch >= 384 ? 4 : (batch >= 192 ? 8 : (batch >= 96 ? 16 : std::clamp(256 / std::max(1, batch), 1, 48)));
+            // (after the top fronts were regrouped against their launch's LDS the top got cheaper: 512 instances now prefer 8 parts, 4.47 against
+            //  4.55 ms per iteration; 1 024 stay at 4 -- 8 parts take 0.65 ms off the dominant pair and put 0.6 ms on the top: profiles/sweep_r03_b128.log)
+            so.n_parts = batch >= 768 ? 4 : (batch >= 192 ? 8 : (batch >= 96 ? 16 : std::clamp(256 / std::max(1, batch), 1, 48)));
             so.part_cut = 1.0;
             so.nd_leaf = 10;  // finer dissection: fewer, better-shaped fronts on big meshes (-3.6 % per iteration on M10k, profiles/sweep_r02_leaf.log);
                               // small circuits keep 24 (their whole graph is one minimum-degree leaf, as validated by every golden)
