@@ -123,7 +123,8 @@ namespace pe_eng PE_ENG_HIDDEN
             // (the population rule counts the instances the GEOMETRY was chosen for -- knob GEOMETRY_BATCH: the host emulation runs the
             //  launch plan of a large sweep on one instance, tests/test_host_logic.py)
             int const gbatch = geometry_batch(h, batch);
-            for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * gbatch <= 320)) ? 1 : 0;
+            int const wide_wgs = std::max(0, knob(h, "TOP_WIDE_WGS", 320));  // (CUs + 25 %; developer knob for A/B runs)
+            for(int l = 0; l < 64; ++l) V.top_wide[l] = (l < V.n_top_levels && wide_knob && (!V.high_occupancy || V.top_cnt[l] * gbatch <= wide_wgs)) ? 1 : 0;
             // levels that hold a front formed against a CU's whole LDS (regroup_wide_top): wide whatever their population, 2 = every
             // front of the level is laid out against the larger cap
             // ... 3 = fronts formed against half a CU's LDS at a level that is not wide by its population: the 8-wavefront launch
@@ -329,7 +330,7 @@ namespace pe_eng PE_ENG_HIDDEN
         {
             long long const wgs = static_cast<long long>(S.top_ptr[l + 1] - S.top_ptr[l]) * gb;
             // whole CU: the rule of V.top_wide; half a CU: the 8-wavefront launch, two workgroups per CU
-            int const cls = (!so.shared_cu || wgs <= 320) ? 1 : ((half_knob && wgs <= half_wgs) ? 2 : 0);
+            int const cls = (!so.shared_cu || wgs <= std::max(0, knob(h, "TOP_WIDE_WGS", 320))) ? 1 : ((half_knob && wgs <= half_wgs) ? 2 : 0);
             if(cls == 0) continue;
             for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k)
             {
