@@ -7,6 +7,8 @@
  * Reference interfaces replaced (paths relative to the reference tree):
  *   include/phy_engine/circuits/solver/cuda_sparse_lu.h:465-473   cuda_sparse_lu::solve_csr_real(...)
  *        -> pe_hip_solve_csr_real()             (same arguments, host pointers, caller-owned)
+ *   include/phy_engine/circuits/solver/cuda_sparse_lu.h:295-312   cuda_sparse_lu::solve_csr / solve_csr_timed on std::complex<double>
+ *        -> pe_hip_solve_csr_complex()          (same arguments; the complex arrays as interleaved doubles)
  *   include/phy_engine/circuits/solver/cuda_sparse_lu.h:27-34     struct timings
  *        -> pe_hip_timings
  *   include/phy_engine/circuits/circuit.h:1122-1482               the CUDA branch of circult::solve_once
@@ -165,6 +167,19 @@ const char* pe_hip_last_error(pe_hip_engine* h); /* valid until the next call on
  * copy_pattern != 0: (re)analyse the pattern; == 0: reuse the cached analysis (same n/nnz/pattern). */
 int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, const int* col_ind, const double* values,
                           const double* b, double* x, int copy_pattern, pe_hip_timings* out);
+
+/* ---- drop-in for the complex twin cuda_sparse_lu::solve_csr_timed / solve_csr on std::complex<double> (cuda_sparse_lu.h:295-312), which
+ * circult::solve_once calls when the stamped system is not all-real (circuit.h:1332: AC / ACOP).  values_re_im / b_re_im / x_re_im are
+ * the arrays of std::complex<double> the reference passes, seen as interleaved (re, im) doubles: 2 nnz, 2 n and 2 n of them.  Solved in
+ * real-equivalent form [Ar -Ai; Ai Ar] by the kernels of the real seam + fp64 iterative refinement on the device; copy_pattern as above
+ * (a cached pattern keeps its pivot order and is re-analysed once on the current values if a solve with it fails).  Returns
+ * PE_HIP_ERR_SINGULAR / PE_HIP_ERR_INACCURATE where the reference's solver returns false. */
+int pe_hip_solve_csr_complex(pe_hip_engine* h, int n, int nnz, const int* row_ptr, const int* col_ind, const double* values_re_im,
+                             const double* b_re_im, double* x_re_im, int copy_pattern, pe_hip_timings* out);
+
+/* Build id of this library: 16 hex digits of a sha256 over its sources, headers and compile flags (csrc/Makefile).  bench.py prints it and
+ * every profile summary under profiles/ carries it, so a figure can be tied to the library that produced it. */
+const char* pe_hip_build_id(void);
 
 /* ---- resident path */
 int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch, int n_tables, const pe_hip_device_table* tables);

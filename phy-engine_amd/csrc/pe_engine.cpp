@@ -716,6 +716,16 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
     return PE_HIP_OK;
 }
 
+// (pe_build_id.hpp is generated by csrc/Makefile; the host emulation of tests/emu is not a build of the library and says so)
+#if __has_include("pe_build_id.hpp")
+    #include "pe_build_id.hpp"
+#elif defined(PE_REQUIRE_BUILD_ID)
+    #error "pe_build_id.hpp missing: build through phy-engine_amd/csrc/Makefile"
+#else
+    #define PE_BUILD_ID "host-emulation"
+#endif
+const char* pe_hip_build_id(void) { return PE_BUILD_ID; }
+
 int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, const int* col_ind, const double* values, const double* b, double* x,
                           int copy_pattern, pe_hip_timings* out)
 {

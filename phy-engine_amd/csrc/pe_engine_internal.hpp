@@ -6,6 +6,7 @@
 //   pe_engine_newton.cpp      host-driven Newton / transient loops of the split schedule, residual safety net, pe_hip_analyze_tr / _dc
 //   pe_engine_checkpoint.cpp  pe_hip_checkpoint_*
 //   pe_engine_ac.cpp          pe_hip_analyze_ac / pe_hip_get_solution_ac
+//   pe_engine_seam.cpp        pe_hip_solve_csr_complex (the complex twin of the solver seam)
 #pragma once
 // (the helpers below are shared between the engine's translation units only: not exported from libpe_hip.so)
 #define PE_ENG_HIDDEN __attribute__((visibility("hidden")))
@@ -151,6 +152,19 @@ struct pe_hip_engine
         int n{-1}, nnz{-1};
         bool have{};
     } csr;
+    // ... and its complex twin (pe_engine_seam.cpp): the real-equivalent 2n system, its refinement buffers
+    struct Csrz
+    {
+        Pool pool;
+        pe::Symbolic sym;
+        pe::DevView V{};
+        int n{-1}, nnz{-1};
+        bool have{};
+        bool on_these_values{};            // the pivot order of the cached analysis was matched on the values of the current call
+        std::vector<int> rp2, ci2, pos;    // real-equivalent pattern; the four positions of every complex entry
+        std::vector<double> vals, rhs, x;  // host staging
+        double *d_xacc{}, *d_b0{}, *d_worst{};  // (owned by pool)
+    } csrz;
 };
 
 // a failed HIP call is NOT "no device" unless the runtime says so: out-of-memory at a large batch, a launch failure or a

@@ -1335,6 +1335,38 @@ namespace pe
         return hipGetLastError();
     }
 
+    // ---- complex twin of the solver seam (pe_engine_seam.cpp pe_hip_solve_csr_complex): refinement residual of the real-equivalent system
+    // kept in CSR order -- r = b0 - A xacc straight into V.rhs (what the correction solve permutes into w), *worst = max componentwise
+    // backward error |r_i| / (|b_i| + sum_j |a_ij x_j|)
+    __global__ void __launch_bounds__(256) k_csr_residual(DevView V, double const* __restrict__ xacc, double const* __restrict__ b0, double* worst)
+    {
+        GridTeam tm;
+        double w = 0.0;
+        for(int r = tm.tid(); r < V.rows; r += tm.size())
+        {
+            double acc = b0[r], mag = fabs(acc);
+            int const e1 = V.csr_rp[r + 1];
+            for(int e = V.csr_rp[r]; e < e1; ++e)
+            {
+                double const t = V.aval[e] * xacc[V.csr_ci[e]];
+                acc -= t;
+                mag += fabs(t);
+            }
+            V.rhs[r] = acc;
+            w = fmax(w, fabs(acc) / (mag > 0.0 ? mag : 1.0));
+        }
+        w = WaveOps{}.wave_max(w);
+        if((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(worst), static_cast<unsigned long long>(__double_as_longlong(fabs(w))));
+    }
+    hipError_t launch_csr_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, double* worst)
+    {
+        hipError_t const e = hipMemsetAsync(worst, 0, sizeof(double), st);
+        if(e != hipSuccess) return e;
+        int const g = std::max(1, std::min(64, (V.rows + 255) / 256));
+        hipLaunchKernelGGL(k_csr_residual, dim3(g), dim3(256), 0, st, V, xacc, b0, worst);
+        return hipGetLastError();
+    }
+
     // ---- on-box HBM ceiling: device-to-device stream copy, 16 B per lane.  Shape from scripts/copy_sweep.hip (round 3): every
     // workgroup owns a contiguous chunk, eight loads in flight per lane, non-temporal loads and stores -- 5.2-5.3 TB/s on these boxes
     // (grid-stride with four in flight, round 2: 4.4-4.7; hipMemcpyDtoD: 5.0; the guide's float4 copy: 6.29, MI355X_MICROARCH.md:36)

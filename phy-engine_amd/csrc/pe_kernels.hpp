@@ -31,6 +31,9 @@ namespace pe
     hipError_t launch_ac_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, int rhs0, double* worst);
     // xacc = first ? x : xacc + x  (every instance; x = the engine's current solution);  first also keeps b0 = the stamped right-hand side
     hipError_t launch_ac_accumulate(hipStream_t st, DevView const& V, double* xacc, double* b0, bool first);
+    // complex twin of the solver seam (batch 1, aval in CSR order, V.csr_rp / V.csr_ci set): V.rhs = b0 - A xacc, *worst (device, one double) = max
+    // componentwise backward error
+    hipError_t launch_csr_residual(hipStream_t st, DevView const& V, double const* xacc, double const* b0, double* worst);
     // per-row {sum v, sum v^2, min, max} of x over the instances (the payload of the sweep's one exchange step):
     // `partial` holds n_chunks x 4 x rows doubles, `out` 4 x rows (both device memory); deterministic (fixed chunk order)
     hipError_t launch_sweep_statistics(hipStream_t st, DevView const& V, int n_chunks, double* partial, double* out);

@@ -22,7 +22,7 @@ MODE_OP, MODE_DC, MODE_TR, MODE_TROP = 0, 1, 4, 5
 OK, ERR_ARG, ERR_NO_DEVICE, ERR_SINGULAR, ERR_NO_CONVERGENCE, ERR_INTERNAL, ERR_INACCURATE = 0, -1, -2, -3, -4, -5, -6
 
 EXPORTS = [
-    "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real",
+    "pe_hip_device_count", "pe_hip_create", "pe_hip_destroy", "pe_hip_last_error", "pe_hip_solve_csr_real", "pe_hip_solve_csr_complex", "pe_hip_build_id",
     "pe_hip_load_circuit", "pe_hip_set_options", "pe_hip_get_info", "pe_hip_set_digital_drives", "pe_hip_set_overlay", "pe_hip_set_knob", "pe_hip_get_knob", "pe_hip_update_param",
     "pe_hip_reset", "pe_hip_analyze_dc", "pe_hip_analyze_tr", "pe_hip_get_solution", "pe_hip_set_solution",
     "pe_hip_get_instance_state", "pe_hip_sweep_statistics", "pe_hip_measure_hbm_ceiling", "pe_hip_get_safety_net_counters", "pe_hip_get_newton_trace", "pe_hip_get_matrix", "pe_hip_analyze_pattern",
@@ -103,6 +103,9 @@ def lib():
         l.pe_hip_solve_csr_real.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
                                             C.POINTER(Timings)]
+        l.pe_hip_solve_csr_complex.argtypes = l.pe_hip_solve_csr_real.argtypes
+        l.pe_hip_build_id.restype = C.c_char_p
+        l.pe_hip_build_id.argtypes = []
         l.pe_hip_analyze_pattern.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(Info)]
         _lib = l
     return _lib
@@ -413,6 +416,24 @@ class Engine:
         self._chk(lib().pe_hip_solve_csr_real(self._h, n, len(ci), _ip(rp), _ip(ci), _dp(va), _dp(bb), _dp(x), 1 if copy_pattern else 0,
                                               C.byref(tm)))
         return x, {k: getattr(tm, k) for k, _ in tm._fields_}
+
+    def solve_csr_complex(self, n, row_ptr, col_ind, values, b, copy_pattern=True):
+        """pe_hip_solve_csr_complex: complex128 arrays travel as the interleaved (re, im) doubles std::complex<double> is."""
+        rp = np.ascontiguousarray(row_ptr, dtype=np.int32)
+        ci = np.ascontiguousarray(col_ind, dtype=np.int32)
+        va = np.ascontiguousarray(values, dtype=np.complex128)
+        bb = np.ascontiguousarray(b, dtype=np.complex128)
+        x = np.empty(n, dtype=np.complex128)
+        tm = Timings()
+        self._chk(lib().pe_hip_solve_csr_complex(self._h, n, len(ci), _ip(rp), _ip(ci), va.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 bb.ctypes.data_as(C.POINTER(C.c_double)), x.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 1 if copy_pattern else 0, C.byref(tm)))
+        return x, {k: getattr(tm, k) for k, _ in tm._fields_}
+
+
+def build_id():
+    """16 hex digits identifying the loaded library build (pe_hip_build_id)."""
+    return lib().pe_hip_build_id().decode()
 
 
 class Sweep:

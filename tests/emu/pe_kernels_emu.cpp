@@ -399,6 +399,25 @@ namespace pe
         }
         return hipSuccess;
     }
+    hipError_t launch_csr_residual(hipStream_t, DevView const& V, double const* xacc, double const* b0, double* worst)
+    {
+        double w = 0.0;
+        for(int r = 0; r < V.rows; ++r)
+        {
+            double acc = b0[r], mag = std::fabs(acc);
+            for(int e = V.csr_rp[r]; e < V.csr_rp[r + 1]; ++e)
+            {
+                double const t = V.aval[e] * xacc[V.csr_ci[e]];
+                acc -= t;
+                mag += std::fabs(t);
+            }
+            V.rhs[r] = acc;
+            double const wb = std::fabs(acc) / (mag > 0.0 ? mag : 1.0);
+            w = (wb > w || wb != wb) ? wb : w;
+        }
+        *worst = w;
+        return hipSuccess;
+    }
     hipError_t launch_stream_copy(hipStream_t, void const* src, void* dst, size_t bytes)
     {
         std::memcpy(dst, src, bytes);

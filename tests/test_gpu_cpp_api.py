@@ -9,6 +9,8 @@ exit 0 = pass, the idiom of the reference's test/CMakeLists.txt:42-64):
   dll_smoke       test/0008.dll/dll_main_smoke.cpp
   linear_models   the known answers of test/0005.models/{vccs_dc,vcvs_gain,cccs_dc,ccvs_dc,op_amp_follower,transformer_ratio,
                   transformer_center_tap_ratio,switch_r_open,generator_dc,coupled_inductors_TR,relay_hysteresis}.cpp
+  hip_sparse_lu_seam  the solver-seam binding of INTEGRATION.md section A as written there: is_available / solve_csr_real / the complex
+                  solve_csr_timed + solve_csr (cuda_sparse_lu.h:295-312, 465-473; circuit.h:1134, 1320, 1332), cached patterns, a singular system
   dll_elements / transistors / dll_mixed_signal / dll_digital_blocks   the loader's element codes 7-23, 50-53, 19 + 200-212, 220-229 (dll_api.h:51-135)
 The same programs also run on the CPU against the host emulation of the kernels (tests/emu) to check the host-side logic.
 """
@@ -20,7 +22,7 @@ import pytest
 from parity_common import ROOT, make
 
 CPP = os.path.join(ROOT, "tests", "cpp")
-TESTS = ["known_answers", "user_model_overlay", "overlay_batch", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks"]  # adc_flash: checked against the golden below
+TESTS = ["known_answers", "user_model_overlay", "overlay_batch", "bridge_tr", "dll_smoke", "linear_models", "dll_elements", "transistors", "dll_mixed_signal", "ac_lowpass", "dll_digital_blocks", "hip_sparse_lu_seam"]  # adc_flash: checked against the golden below
 
 
 @pytest.fixture(scope="module")

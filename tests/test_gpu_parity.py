@@ -249,6 +249,57 @@ def test_solve_csr_real_seam_large_front(eng):
     assert np.max(np.abs(A @ x - b)) < 1e-9
 
 
+def complex_csr_of_ac_point(o, omega):
+    """The complex CSR the reference's solve_once would hand to its solver at this AC point (sorted columns, circuit.h:1171-1226)."""
+    import scipy.sparse as sp
+    A, rhs = o.stamp_ac(omega)
+    keys = sorted(A.keys())
+    M = sp.csr_matrix((np.array([A[q] for q in keys], dtype=complex), (np.array([q[0] for q in keys]), np.array([q[1] for q in keys]))),
+                      shape=(o.rows, o.rows))
+    M.sort_indices()
+    return M, rhs
+
+
+def test_solve_csr_complex_seam(eng, oracle_mod):
+    """Drop-in for the complex twin cuda_sparse_lu::solve_csr_timed (cuda_sparse_lu.h:304-312, called at circuit.h:1332 when the stamped
+    system is not all-real): the assembled complex system of every frequency point of the real-reference golden `ac_rlc_diode_acop`
+    goes through pe_hip_solve_csr_complex -- first call analyses the pattern, the later ones reuse it (copy_pattern = 0) -- and must
+    land on the golden phasors; then a 1 600-node R-C mesh at one frequency against a CPU complex sparse LU."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    meta, gx, deck = golden("ac_rlc_diode_acop")
+    g = golden_complex(meta, gx)
+    o = oracle_mod.Oracle(deck)
+    o.g_min = meta["gmin"]
+    o.prepare()
+    assert o.solve("OP") >= 0
+    for k, w in enumerate(meta["omegas"]):
+        M, rhs = complex_csr_of_ac_point(o, w)
+        x, tm = eng.solve_csr_complex(o.rows, M.indptr, M.indices, M.data, rhs, copy_pattern=(k == 0))
+        assert np.all(np.abs(x - g[k]) <= 1e-9 + 1e-6 * np.abs(g[k])), (w, x, g[k])
+    # G + j omega C of a 40 x 40 mesh (diagonally dominant in modulus, entries of both kinds in every row), cached-pattern second call
+    mdeck = pe.deck.rc_mesh(40, 40, 5, False)
+    mo = oracle_mod.Oracle(mdeck)
+    mo.update_tr_step(1e-10)
+    mo.t = 1e-10
+    A, b = mo.assemble("TR")
+    A = A.tocsr()
+    A.sort_indices()
+    rng = np.random.default_rng(3)
+    Z = sp.csr_matrix((A.data * (1.0 + 1j * rng.uniform(-2.0, 2.0, A.nnz)), A.indices, A.indptr), shape=A.shape)
+    bz = b * (1.0 - 0.5j) + 1j * rng.standard_normal(len(b)) * 1e-3
+    x, _ = eng.solve_csr_complex(Z.shape[0], Z.indptr, Z.indices, Z.data, bz, copy_pattern=True)
+    xr = spla.splu(Z.tocsc()).solve(bz)
+    assert np.max(np.abs(x - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr)))
+    assert np.max(np.abs(Z @ x - bz)) <= 1e-12 * max(1.0, np.max(np.abs(bz)))
+    x2, _ = eng.solve_csr_complex(Z.shape[0], Z.indptr, Z.indices, Z.data * (2.0 - 1.0j), bz, copy_pattern=False)
+    assert np.max(np.abs((2.0 - 1.0j) * x2 - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr)))
+    # a singular complex system is refused, like the reference's `return false`
+    S = sp.csr_matrix(np.array([[1.0 + 1.0j, 2.0 + 2.0j], [2.0 + 2.0j, 4.0 + 4.0j]]))
+    with pytest.raises(pe.ffi.PeHipError):
+        eng.solve_csr_complex(2, S.indptr, S.indices, S.data, np.array([1.0, 1.0j]), copy_pattern=True)
+
+
 def test_stamped_matrix_matches_oracle(eng, oracle_mod):
     """The device-side MNA gather reproduces the oracle's assembled matrix entry by entry (values and pattern)."""
     deck = pe.deck.rc_mesh(16, 16, 9, True)

@@ -374,6 +374,48 @@ assert np.max(np.abs(x2 - spla.splu(L.tocsc()).solve(b2))) < 1e-9
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
 
 
+def test_complex_solver_seam_under_host_emulation(emu_lib):
+    """pe_hip_solve_csr_complex (the twin of cuda_sparse_lu::solve_csr_timed, cuda_sparse_lu.h:304-312) on the host emulation: the
+    assembled complex systems of the `ac_rlc_diode_acop` golden (first call analyses, later calls reuse the pattern and fall back to a
+    re-analysis when the cached pivot order does not suit the new frequency), a complex mesh against scipy, a singular system."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})
+import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+from parity_common import *
+orc = pe_load.load_oracle()
+meta, gx, deck = golden('ac_rlc_diode_acop')
+g = golden_complex(meta, gx)
+o = orc.Oracle(deck); o.g_min = meta['gmin']; o.prepare(); assert o.solve('OP') >= 0
+eng = pe.ffi.Engine()
+for k, w in enumerate(meta['omegas']):
+    A, rhs = o.stamp_ac(w)
+    keys = sorted(A.keys())
+    M = sp.csr_matrix((np.array([A[q] for q in keys], dtype=complex), (np.array([q[0] for q in keys]), np.array([q[1] for q in keys]))), shape=(o.rows, o.rows))
+    M.sort_indices()
+    x, tm = eng.solve_csr_complex(o.rows, M.indptr, M.indices, M.data, rhs, copy_pattern=(k == 0))
+    assert np.all(np.abs(x - g[k]) <= 1e-9 + 1e-6 * np.abs(g[k])), (w, x, g[k])
+mo = orc.Oracle(pe.deck.rc_mesh(16, 16, 5, False)); mo.update_tr_step(1e-10); mo.t = 1e-10
+A, b = mo.assemble('TR'); A = A.tocsr(); A.sort_indices()
+rng = np.random.default_rng(3)
+Z = sp.csr_matrix((A.data * (1.0 + 1j * rng.uniform(-2.0, 2.0, A.nnz)), A.indices, A.indptr), shape=A.shape)
+bz = b * (1.0 - 0.5j) + 1j * rng.standard_normal(len(b)) * 1e-3
+x, _ = eng.solve_csr_complex(Z.shape[0], Z.indptr, Z.indices, Z.data, bz, copy_pattern=True)
+xr = spla.splu(Z.tocsc()).solve(bz)
+assert np.max(np.abs(x - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr)))
+x2, _ = eng.solve_csr_complex(Z.shape[0], Z.indptr, Z.indices, Z.data * (2.0 - 1.0j), bz, copy_pattern=False)
+assert np.max(np.abs((2.0 - 1.0j) * x2 - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr)))
+S = sp.csr_matrix(np.array([[1.0 + 1.0j, 2.0 + 2.0j], [2.0 + 2.0j, 4.0 + 4.0j]]))
+try:
+    eng.solve_csr_complex(2, S.indptr, S.indices, S.data, np.array([1.0, 1.0j]), copy_pattern=True)
+    raise SystemExit('a singular complex system was accepted')
+except pe.ffi.PeHipError as e:
+    assert e.code in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_INACCURATE), e.code
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=600)
+
+
 def test_failed_solve_is_not_sticky_under_host_emulation(emu_lib):
     """circuit.h:242-254: a failed transient rolls tr_duration back and returns false; the NEXT analyze() tries again from that
     state.  Here: the g_min = 0 bridge fails (singular with all four diodes off), the caller raises g_min, and the same resident
