@@ -144,6 +144,8 @@ typedef struct pe_hip_info
     int n_wave_fronts;           /* fronts below the cooperative part of the tree (one wavefront each) ... */
     int n_quad_fronts;           /* ... of which the lane-group kernel k_m2_factor_quads factors (four instances per wavefront); 0: not in use */
     long long nnz_lu_stored_quad; /* part of nnz_lu_stored held by those fronts */
+    int mid_top_limit, ew_grid, quad_lds_pad; /* launch-shape knobs MID_TOP / EW_GRID / QUAD_LDS in effect for THIS engine's resident circuit
+                                                 (pe_hip_set_knob, else the environment, else the default; 0 = rule of the policy) */
 } pe_hip_info;
 
 typedef struct pe_hip_run_stats
@@ -207,7 +209,7 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
  * cells / right-hand-side rows discovered once (what mna_keep_pattern_ready does, circuit.h:993-1003); the values are uploaded
  * and ADDED to the device-side stamp.  The hooks read node voltages, so the Newton loop of such a circuit is driven from the
  * host (one callback + one small upload per iteration and instance).  In a batch every group of calls is preceded by
- * PE_HIP_OVERLAY_INSTANCE with the instance index in `mode` (see below); small-signal AC with an overlay needs batch = 1.
+ * PE_HIP_OVERLAY_INSTANCE with the instance index in `mode` (see below) -- small-signal AC included (one PE_HIP_OVERLAY_AC call per instance).
  *   rows / cols / rhs_rows  absolute MNA indices, 0-based: nodes 0 .. n_nodes-1, then branches (mna.h:60-157 G/B/C/D/I/E layout)
  *   representative          |value| per cell for the static pivot matching (the discovery stamp), may be NULL
  *   nonlinear               1: the circuit needs Newton iterations even without a built-in non-linear device

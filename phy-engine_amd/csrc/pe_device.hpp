@@ -128,8 +128,17 @@ namespace pe
                                 // fronts formed against that LDS); 3: one 8-wavefront workgroup per front with half a CU's LDS (k_m2_factor_top_mid)
         int lds_top_doubles{};  // dynamic LDS of the 16-wavefront launches, in doubles (>= lds_doubles)
         int lds_mid_doubles{};  // ... of the 8-wavefront launches of the levels marked 3
+        // launch-shape knobs of THIS engine (pe_hip_set_knob / PHY_ENGINE_HIP_*; read once per analysis into the view, never from the
+        // environment at launch time): levels of at most mid_top_limit workgroups run the 8-wavefront launch; ew_grid > 0 forces the
+        // workgroups per instance of the elementwise kernels; quad_lds_pad pads the lane-group kernel's LDS request (occupancy probe)
+        int mid_top_limit{512}, ew_grid{}, quad_lds_pad{};
+        int top_run_any_class{};  // TEST knob (TEST_OLD_TOP_RUNS): runs of single-front levels join levels of different LDS classes -- the
+                                  // round-3 grouping bug, kept reachable so that the LDS guard can be shown to refuse it
+        int const* f_need{};      // per front: doubles of LDS its layout occupies (image or panels + right-hand-side column; 0 for a chain
+                                  // link continued in its child's image) -- compared with the LDS its launch really has (flag bit 3)
         int* active;            // [.] multi-workgroup mode: instances still iterating
-        int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot
+        int* flags;             // [.] multi-workgroup mode: bit 0 non-finite solution, bit 1 Newton violation, bit 2 bad pivot,
+                                //     bit 3 a front's LDS layout does not fit the launch that runs it (internal error, never "singular")
         int high_occupancy;     // 1: launch the 128-VGPR kernel variant (several workgroups per CU)
         int keep_l21;           // 1: a later launch may reuse the factors with a separate forward pass (linear circuit, refactor_every_solve = 0)
         int wave_m, wave_p, max_m, max_p;

@@ -439,6 +439,9 @@ int pe_hip_get_info(pe_hip_engine* h, pe_hip_info* out)
             if(h->sym.f_kind[s] == 2) out->nnz_lu_stored_top += 2LL * h->sym.f_p[s] * h->sym.f_u[s] + static_cast<long long>(h->sym.f_p[s]) * h->sym.f_p[s];
         out->n_row_swaps = h->sym.n_row_swaps;
         out->factor_flops = h->sym.flops;
+        out->mid_top_limit = h->V.mid_top_limit;
+        out->ew_grid = h->V.ew_grid;
+        out->quad_lds_pad = h->V.quad_lds_pad;
     }
     out->bytes_per_instance = static_cast<long long>((h->circ_pool.bytes + h->sym_pool.bytes) / std::max(1, hc.batch));
     return PE_HIP_OK;

@@ -51,21 +51,30 @@ int pe_hip_analyze_ac(pe_hip_engine* h, double omega, pe_hip_run_stats* st)
     if(!op.d_geq.empty()) HIPCHK(h, hipMemcpy(op.d_geq.data(), h->V.d_geq, op.d_geq.size() * sizeof(double), hipMemcpyDeviceToHost));
     if(!op.dv.empty()) HIPCHK(h, hipMemcpy(op.dv.data(), h->V.dv, op.dv.size() * sizeof(double), hipMemcpyDeviceToHost));
     if(!op.rl_engaged.empty()) HIPCHK(h, hipMemcpy(op.rl_engaged.data(), h->V.rl_engaged, op.rl_engaged.size() * sizeof(int), hipMemcpyDeviceToHost));
-    if(has_overlay(h))
-    {
-        if(hc.batch > 1) return fail(h, PE_HIP_ERR_ARG, "analyze_ac: a host-stamp overlay needs batch = 1 for small-signal analysis");
-        // host-stamped models: their iterate_ac hooks stamp complex values at this omega around the operating point held in x
-        op.ov_a.assign(2 * static_cast<size_t>(hc.n_ov_a), 0.0);
-        op.ov_b.assign(2 * static_cast<size_t>(hc.n_ov_b), 0.0);
-        h->ov_x.resize(static_cast<size_t>(hc.rows));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
-        if(h->overlay_fn(h->overlay_user, PE_HIP_OVERLAY_AC, PE_HIP_MODE_OP, omega, 0.0, h->ov_x.data(), op.ov_a.data(), op.ov_b.data()) != 0)
-            return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: host-stamp overlay: a model's iterate_ac hook failed");
-    }
     auto const& ah = A.circ.hc;
     std::vector<double> dv(static_cast<size_t>(B) * ah.dv_len);
-    for(int b = 0; b < B; ++b) pe::fill_ac_values(hc, A.circ, op, b, omega, h->opt.g_min, r_open_of(h), &dv[static_cast<size_t>(b) * ah.dv_len]);
+    if(has_overlay(h))
+    {
+        h->ov_x.resize(static_cast<size_t>(hc.rows));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    for(int b = 0; b < B; ++b)
+    {
+        if(has_overlay(h))
+        {
+            // host-stamped models: their iterate_ac hooks stamp complex values at this omega around the operating point held in x -- per
+            // instance, as the transient path does (PE_HIP_OVERLAY_INSTANCE tells the callback whose state the call concerns); the
+            // reference runs every model's iterate_ac in its AC loop, circuit.h:389-431
+            if(B > 1 && h->overlay_fn(h->overlay_user, PE_HIP_OVERLAY_INSTANCE, b, omega, 0.0, nullptr, nullptr, nullptr) != 0)
+                return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: host-stamp overlay: the callback refused PE_HIP_OVERLAY_INSTANCE (it does not support batches)");
+            op.ov_a.assign(2 * static_cast<size_t>(hc.n_ov_a), 0.0);
+            op.ov_b.assign(2 * static_cast<size_t>(hc.n_ov_b), 0.0);
+            HIPCHK(h, hipMemcpy(h->ov_x.data(), h->V.x + static_cast<size_t>(b) * hc.rows, static_cast<size_t>(hc.rows) * sizeof(double), hipMemcpyDeviceToHost));
+            if(h->overlay_fn(h->overlay_user, PE_HIP_OVERLAY_AC, PE_HIP_MODE_OP, omega, 0.0, h->ov_x.data(), op.ov_a.data(), op.ov_b.data()) != 0)
+                return fail(h, PE_HIP_ERR_INTERNAL, "analyze_ac: host-stamp overlay: a model's iterate_ac hook failed");
+        }
+        pe::fill_ac_values(hc, A.circ, op, b, omega, h->opt.g_min, r_open_of(h), &dv[static_cast<size_t>(b) * ah.dv_len]);
+    }
     // The pivot order is static (row matching + ordering on representative values): it is (re)made on the values of
     // instance 0 at this frequency when there is none yet, when omega moved more than a decade away from the one it was made
     // for (reactive entries scale with omega), or when a solve with a stale order hits a bad pivot.

@@ -321,6 +321,7 @@ namespace pe_eng PE_ENG_HIDDEN
             {
                 if(!S.active[b]) continue;
                 int const f = S.flags[b];
+                if(f & 8) return fail(h, PE_HIP_ERR_INTERNAL, "a front's LDS layout exceeds the LDS of the launch that ran it (launch plan / layout mismatch)");
                 if(f & 5) result[b] = PE_HIP_ERR_SINGULAR;
                 else if(!h->hc.nonlinear || !(f & 2))
                 {

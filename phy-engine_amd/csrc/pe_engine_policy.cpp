@@ -2,6 +2,7 @@
 // many wavefronts, parts, pivots and LDS doubles by batch size (measured sweeps under profiles/), the PHY_ENGINE_HIP_* tuning knobs
 // (INTEGRATION.md), the analysis with its LDS-fit escalation, and the upload of its tables.
 #include "pe_engine_internal.hpp"
+#include "pe_top_plan.hpp"
 
 using namespace pe_eng;
 
@@ -38,6 +39,37 @@ namespace pe_eng PE_ENG_HIDDEN
     {
         if(S.f_kind[s] == 0 || (S.f_p[s] <= so.max_pivots && panel_need(S.f_p[s], S.f_u[s]) <= so.panel_doubles)) return 0;
         return (so.panel_doubles_mid > 0 && panel_need(S.f_p[s], S.f_u[s]) <= so.panel_doubles_mid) ? 3 : 2;
+    }
+
+    // The reference's contract for its solver is "return false, never corrupt" (circuit.h:1517).  A front whose LDS layout -- fixed by
+    // build_assembly_lists against the cap of the launch class its level was GIVEN -- exceeds the dynamic LDS of the launch that will
+    // actually RUN it would read zeros and drop writes beyond the workgroup's allocation on gfx950 (scripts/lds_oob_probe.hip) without
+    // any fault.  So the plan is checked where it is made: every wave front against a wavefront's slot, every cooperative front of a
+    // part against the parts' launch, every top front against the launch for_each_top_launch (pe_top_plan.hpp, the launcher's own
+    // plan) puts its level on.  A mismatch refuses the load with PE_HIP_ERR_INTERNAL.
+    static int check_lds_plan(pe_hip_engine* h, pe::Symbolic const& S, pe::DevView const& V, std::vector<int> const& need, int batch)
+    {
+        auto refuse = [&](int s, char const* what, long long have)
+        {
+            return fail(h, PE_HIP_ERR_INTERNAL,
+                        "launch plan: front " + std::to_string(s) + " (order " + std::to_string(S.f_p[s] + S.f_u[s]) + ", " + std::to_string(S.f_p[s]) + " pivots, layout " +
+                            std::to_string(S.f_mode[s]) + ") needs " + std::to_string(need[static_cast<size_t>(s)]) + " doubles of LDS, " + what + " has " + std::to_string(have));
+        };
+        for(int s = 0; s < S.nfronts; ++s)
+        {
+            if(S.f_kind[s] == 0 && need[static_cast<size_t>(s)] > V.lds_slot) return refuse(s, "a wavefront's slot", V.lds_slot);
+            if(S.f_kind[s] == 1 && need[static_cast<size_t>(s)] > V.lds_doubles - 2) return refuse(s, "the parts' launch", V.lds_doubles - 2);
+        }
+        int rc = PE_HIP_OK;
+        pe::for_each_top_launch(V, batch, V.high_occupancy && V.n_waves == 4, V.mid_top_limit,
+                                [&](pe::TopLaunch const& t)
+                                {
+                                    for(int l = t.level; l < t.level + t.nlev && rc == PE_HIP_OK; ++l)
+                                        for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1] && rc == PE_HIP_OK; ++k)
+                                            if(int const s = S.top_list[k]; need[static_cast<size_t>(s)] > t.lds_doubles - 2)
+                                                rc = refuse(s, t.kind == 1 ? "its 16-wavefront launch" : (t.kind == 0 ? "its 4-wavefront launch" : "its 8-wavefront launch"), t.lds_doubles - 2);
+                                });
+        return rc;
     }
 
     int upload_symbolic(pe_hip_engine* h, Pool& pool, pe::Symbolic& S, pe::SymbolicOptions const& so, pe::DevView& V, int batch)
@@ -142,6 +174,19 @@ namespace pe_eng PE_ENG_HIDDEN
         }
         HIPCHK(h, pool.upload(V.f_mode, S.f_mode));
         HIPCHK(h, pool.upload(V.f_keep, S.f_keep));
+        // launch-shape knobs of this engine travel in the view (pe_kernels.hip reads no environment)
+        V.mid_top_limit = knob(h, "MID_TOP", 512);
+        V.ew_grid = std::max(0, knob(h, "EW_GRID", 0));
+        V.quad_lds_pad = std::max(0, knob(h, "QUAD_LDS", 0));
+        V.top_run_any_class = knob(h, "TEST_OLD_TOP_RUNS", 0) != 0 ? 1 : 0;
+        // LDS guard: what every front's layout occupies, checked here against the launch that will run it (a host loop over the
+        // fronts) and once more on the device against the LDS the launch really received (k_m2_factor_top*: flag bit 3)
+        {
+            std::vector<int> need(static_cast<size_t>(S.nfronts), 0);
+            for(int s = 0; s < S.nfronts; ++s) need[static_cast<size_t>(s)] = static_cast<int>(pe::front_lds_need(S.f_mode[s], S.f_p[s], S.f_u[s]));
+            if(int const rc = check_lds_plan(h, S, V, need, batch); rc != PE_HIP_OK) return rc;
+            HIPCHK(h, pool.upload(V.f_need, need));
+        }
         HIPCHK(h, pool.upload(V.gl_ptr, S.gl_ptr));
         HIPCHK(h, pool.upload(V.gl_rptr, S.gl_rptr));
         HIPCHK(h, pool.upload(V.gl_sptr, S.gl_sptr));

@@ -648,6 +648,15 @@ namespace pe
         stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
     }
 
+    // LDS guard of the top launches: front s laid out for more LDS than this launch has (V.f_need: image or panels + right-hand-side
+    // column, fixed with the launch plan) -> flag bit 3, nothing is touched.  Wavefront-uniform; one scalar load per front.
+    __device__ __forceinline__ bool lds_overrun(DevView const& V, int b, int s, int lds_doubles)
+    {
+        if(V.f_need[s] <= lds_doubles - 2) return false;
+        if(threadIdx.x == 0) atomicOr(V.flags + b, 8);
+        return true;
+    }
+
     // (the four team kernels of the split schedule come in the two register budgets of the resident kernels: MINW = 2 for few
     // big workgroups, MINW = 4 when several workgroups share a CU)
     template <int MINW>
@@ -672,17 +681,20 @@ namespace pe
     }
 
     template <int MINW>
-    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level, int nlev)
+    __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level, int nlev, int lds_doubles)
     {
         // one workgroup per front of `level`; nlev > 1: a run of single-front levels (a chain at the top of the tree) handled by
         // the same workgroup one after the other -- saves a launch per level where a launch is most of the level's time
+        // lds_doubles: the dynamic LDS THIS launch was given -- the cap of every front it runs; a front whose layout needs more was put
+        // on the wrong launch (flag bit 3: internal error; the host refuses such a plan at load time, upload_symbolic)
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         HipTeam tm;
         for(int l = level; l < level + nlev; ++l)
         {
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            if(!front_factor(tm, V, b, s, pe_lds, V.lds_doubles - 2, 0, true))
+            if(lds_overrun(V, b, s, lds_doubles)) return;
+            if(!front_factor(tm, V, b, s, pe_lds, lds_doubles - 2, 0, true))
             {
                 if(tm.tid() == 0) atomicOr(V.flags + b, 4);
                 return;
@@ -691,7 +703,7 @@ namespace pe
     }
 
     // the same with 16 wavefronts per workgroup: few instances leave the GPU idle, a top front then gets a whole CU's wavefront slots
-    __global__ void __launch_bounds__(1024) k_m2_factor_top_wide(DevView V, int level, int nlev)
+    __global__ void __launch_bounds__(1024) k_m2_factor_top_wide(DevView V, int level, int nlev, int lds_doubles)
     {
         // one workgroup per front of `level`; nlev > 1: a run of single-front levels (a chain at the top of the tree) handled by
         // the same workgroup one after the other -- saves a launch per level where a launch is most of the level's time
@@ -704,7 +716,8 @@ namespace pe
         for(int l = level; l < level + nlev; ++l)
         {
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            if(!front_factor<HipTeam, true>(tm, V, b, s, pe_lds, V.lds_top_doubles - 2, 0, true, &cs))
+            if(lds_overrun(V, b, s, lds_doubles)) return;
+            if(!front_factor<HipTeam, true>(tm, V, b, s, pe_lds, lds_doubles - 2, 0, true, &cs))
             {
                 if(tm.tid() == 0) atomicOr(V.flags + b, 4);
                 return;
@@ -714,7 +727,7 @@ namespace pe
 
     // ... and with 8: a level of 257..512 workgroups fills half of the wavefront slots with 4-wavefront workgroups; two 8-wavefront
     // workgroups per CU use all of them (128 instances x 4 fronts: the lower top levels of the 8-GPU share of the sweep)
-    __global__ void __launch_bounds__(512, 4) k_m2_factor_top_mid(DevView V, int level, int nlev)
+    __global__ void __launch_bounds__(512, 4) k_m2_factor_top_mid(DevView V, int level, int nlev, int lds_doubles)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
@@ -722,8 +735,9 @@ namespace pe
         for(int l = level; l < level + nlev; ++l)
         {
             int const s = V.top_list[V.top_ptr[l] + static_cast<int>(blockIdx.x)];
-            // (a level marked 3 holds fronts formed against half a CU's LDS: two of these workgroups per CU)
-            if(!front_factor(tm, V, b, s, pe_lds, (V.top_wide[l] == 3 ? V.lds_mid_doubles : V.lds_doubles) - 2, 0, true))
+            // (a launch of levels marked 3 -- fronts formed against half a CU's LDS -- has that much: two of these workgroups per CU)
+            if(lds_overrun(V, b, s, lds_doubles)) return;
+            if(!front_factor(tm, V, b, s, pe_lds, lds_doubles - 2, 0, true))
             {
                 if(tm.tid() == 0) atomicOr(V.flags + b, 4);
                 return;
@@ -1067,18 +1081,12 @@ namespace pe
     }
 
     // one Newton iteration of every active instance in the split schedule: stamp -> LU -> solves -> Newton bits.
-    static int getenv_int(char const* name, int def)
-    {
-        char const* v = std::getenv(name);
-        return v && *v ? std::atoi(v) : def;
-    }
-
+    // (no launch reads the environment: every knob arrives in the view, set per engine by pe_engine_policy.cpp)
     // workgroups per instance of the elementwise kernels (eval, stamp, winit, finish, companion): ~2048 rows each for large
     // batches; few instances spread over more workgroups (these kernels are gathers: latency-bound at low occupancy)
     static int grid_per_instance(DevView const& V)
     {
-        static int const forced = getenv_int("PHY_ENGINE_HIP_EW_GRID", 0);  // developer knob (sweeps): workgroups per instance, as given
-        if(forced > 0) return forced;
+        if(V.ew_grid > 0) return V.ew_grid;  // knob EW_GRID of this engine (sweeps): workgroups per instance, as given
         int const by_rows = (V.rows + 2047) / 2048, fine = (V.rows + 255) / 256, want = 512 / (V.batch > 0 ? V.batch : 1);
         int g = by_rows > (want < fine ? want : fine) ? by_rows : (want < fine ? want : fine);
         return g < 1 ? 1 : (g > 64 ? 64 : g);
@@ -1129,8 +1137,8 @@ namespace pe
             // the wave fronts of four instances per wavefront (pe_quad.hpp); k_m2_factor_parts then runs the cooperative fronts only
             if(V.quad && V.n_quads > 0)
             {
-                static int const pad = getenv_int("PHY_ENGINE_HIP_QUAD_LDS", 0);  // developer knob: LDS request that limits the wavefronts per CU
-                size_t const qlds = std::max(static_cast<size_t>(pad), static_cast<size_t>(V.q_lds_stride) * 32);  // four instance stacks
+                // (knob QUAD_LDS of this engine: an LDS request that limits the wavefronts per CU -- occupancy probe)
+                size_t const qlds = std::max(static_cast<size_t>(std::max(0, V.quad_lds_pad)), static_cast<size_t>(V.q_lds_stride) * 32);  // four instance stacks
                 if(qlds > 0)
                 {
                     hipError_t const e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_quads), qlds);
@@ -1144,17 +1152,18 @@ namespace pe
             // 16 wavefronts per front where a level leaves most CUs without a workgroup anyway: always in the one-workgroup-per-CU
             // geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances <= CUs + 25 %);
             // the rule lives in upload_symbolic (the fronts' LDS layout depends on it), the plan in pe_top_plan.hpp
-            static int const mid_knob = getenv_int("PHY_ENGINE_HIP_MID_TOP", 512);
-            for_each_top_launch(V, B, MINW == 4 && T == 256, mid_knob,
+            // (knob MID_TOP of this engine: V.mid_top_limit; the kernels take the launch's LDS as their cap -- never a field of V)
+            for_each_top_launch(V, B, MINW == 4 && T == 256, V.mid_top_limit,
                                 [&](TopLaunch const& t)
                                 {
                                     dim3 const grid(V.top_cnt[t.level], B);
                                     size_t const bytes = static_cast<size_t>(t.lds_doubles) * sizeof(double);
-                                    if(t.kind == 1) hipLaunchKernelGGL(k_m2_factor_top_wide, grid, dim3(1024), bytes, st, V, t.level, t.nlev);
+                                    int const cap = static_cast<int>(t.lds_doubles);
+                                    if(t.kind == 1) hipLaunchKernelGGL(k_m2_factor_top_wide, grid, dim3(1024), bytes, st, V, t.level, t.nlev, cap);
                                     else if(t.kind != 0)
-                                        hipLaunchKernelGGL(k_m2_factor_top_mid, grid, dim3(512), bytes, st, V, t.level, t.nlev);
+                                        hipLaunchKernelGGL(k_m2_factor_top_mid, grid, dim3(512), bytes, st, V, t.level, t.nlev, cap);
                                     else
-                                        hipLaunchKernelGGL(k_m2_factor_top<MINW>, grid, dim3(T), bytes, st, V, t.level, t.nlev);
+                                        hipLaunchKernelGGL(k_m2_factor_top<MINW>, grid, dim3(T), bytes, st, V, t.level, t.nlev, cap);
                                 });
         }
         else

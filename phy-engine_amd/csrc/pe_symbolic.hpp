@@ -18,6 +18,14 @@ namespace pe
     // columns (the column solves of a block step, the B operand of the MFMA tiles: stride = leading dimension) spread over the
     // banks instead of piling onto gcd(2 ld, 64) of them -- ld = 32 puts all 64 lanes of such an access on one bank pair.
     constexpr int pe_ld(int n) { return n | 1; }
+    // LDS doubles the layout of a front occupies in front_factor (pe_front.hpp): the whole image (mode 0) or the pivot panels (modes 1, 2)
+    // + the right-hand-side column of the fused forward substitution; a chain link continued in its child's image (mode 3) adds nothing
+    constexpr long long front_lds_need(int mode, int p, int u)
+    {
+        long long const m = p + u;
+        if(mode == 3) return 0;
+        return (mode == 0 ? static_cast<long long>(pe_ld(p + u)) * m : static_cast<long long>(pe_ld(p + u)) * p + static_cast<long long>(pe_ld(p)) * u) + m;
+    }
 
     struct SymbolicOptions
     {

@@ -23,7 +23,7 @@ namespace pe
     {
         int n = 1;
         if(V.top_cnt[l] == 1)
-            while(l + n < V.n_top_levels && V.top_cnt[l + n] == 1 && top_launch_class(V, l + n) == top_launch_class(V, l)) ++n;
+            while(l + n < V.n_top_levels && V.top_cnt[l + n] == 1 && (V.top_run_any_class || top_launch_class(V, l + n) == top_launch_class(V, l))) ++n;
         return n;
     }
 

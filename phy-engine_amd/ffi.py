@@ -54,7 +54,8 @@ class Info(C.Structure):
                 ("bytes_per_instance", C.c_longlong), ("n_r", C.c_int), ("n_c", C.c_int), ("n_l", C.c_int), ("n_v", C.c_int),
                 ("n_i", C.c_int), ("n_d", C.c_int), ("nonlinear", C.c_int), ("n_parts", C.c_int), ("n_top_levels", C.c_int),
                 ("n_wavefronts", C.c_int), ("lds_bytes", C.c_int), ("nnz_lu_stored_top", C.c_longlong), ("n_wave_fronts", C.c_int),
-                ("n_quad_fronts", C.c_int), ("nnz_lu_stored_quad", C.c_longlong)]
+                ("n_quad_fronts", C.c_int), ("nnz_lu_stored_quad", C.c_longlong), ("mid_top_limit", C.c_int), ("ew_grid", C.c_int),
+                ("quad_lds_pad", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

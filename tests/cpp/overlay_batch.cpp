@@ -7,6 +7,10 @@
 // PE_HIP_OVERLAY_INSTANCE.  One operating point + 6 transient steps on three instances at once must equal the same three instances run
 // one at a time with batch = 1 -- to the last bit: the per-instance arithmetic does not depend on the batch (same kernels, same
 // geometry: the split / host-driven schedule whenever an overlay is present).
+// Round 4: small-signal AC on the batch as well (PE_HIP_OVERLAY_AC per instance behind PE_HIP_OVERLAY_INSTANCE -- the reference runs every
+// model's iterate_ac in its AC loop, circuit.h:389-431): an AC current source drives node 2, the host models stamp their small-signal
+// admittance g + 3 k v_op^2 + j omega C at each instance's own operating point; phasors of the batch = phasors of the single runs bit for
+// bit, and equal to I / (1/R + Y) in closed form.
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -23,6 +27,7 @@ namespace
         double g{1e-3}, cap{2e-9};
         int current{0};
         int instance_events{0};
+        int ac_events{0};
         double dt_now{0.0};
     };
 
@@ -59,6 +64,16 @@ namespace
             m.vlast[i] = v;
             return 0;
         }
+        if(event == PE_HIP_OVERLAY_AC)
+        {
+            // iterate_ac of the two host models at the operating point x (t carries omega): one cell, a = [re | im]
+            double const v = x[1];
+            a[0] = m.g + 3.0 * m.k[i] * v * v;
+            a[1] = t * m.cap;
+            b[0] = b[1] = 0.0;
+            ++m.ac_events;
+            return 0;
+        }
         return 0;  // CONVERGED: accept
     }
 
@@ -70,7 +85,9 @@ namespace
     }
 
     // runs instances [first, first + count) as one batch; returns x of every instance after the DC point and after each TR step
-    bool run(int first, int count, std::vector<double> const& r_all, std::vector<double> const& k_all, std::vector<std::vector<double>>& out, int& instance_events)
+    constexpr double ac_omega = 2.0e5, ac_amp = 1.0e-3;
+    bool run(int first, int count, std::vector<double> const& r_all, std::vector<double> const& k_all, std::vector<std::vector<double>>& out, int& instance_events,
+             std::vector<std::vector<double>>& phasors)
     {
         pe_hip_engine* h{};
         if(!check(pe_hip_create(0, &h), nullptr, "create")) return false;
@@ -82,16 +99,17 @@ namespace
         int const rows1[1] = {1}, cols1[1] = {1}, rhs1[1] = {1};
         double const rep[1] = {1e-3};
         if(!check(pe_hip_set_overlay(h, 1, rows1, cols1, rep, 1, rhs1, /*nonlinear=*/1, &hook, &m), h, "set_overlay")) return false;
-        int const vn[2] = {1, 0}, vb[1] = {0}, rn[2] = {1, 2};
-        double const vpar[1] = {3.0};
+        int const vn[2] = {1, 0}, vb[1] = {0}, rn[2] = {1, 2}, in[2] = {0, 2};
+        double const vpar[1] = {3.0}, ipar[3] = {ac_amp, ac_omega, 0.0};  // (IAC: nothing in OP / DC, Ip sin(omega t) in TR, the phasor Ip in AC)
         std::vector<double> rpar(r_all.begin() + first, r_all.begin() + first + count);  // [batch][1][1]
-        pe_hip_device_table tabs[2]{};
+        pe_hip_device_table tabs[3]{};
         tabs[0] = {PE_HIP_VDC, 1, vn, vb, vpar, 0};
         tabs[1] = {PE_HIP_R, 1, rn, nullptr, rpar.data(), 1};
+        tabs[2] = {PE_HIP_IAC, 1, in, nullptr, ipar, 0};
         pe_hip_options opt{};
         opt.g_min = 1e-12;
         if(!check(pe_hip_set_options(h, &opt), h, "set_options")) return false;
-        if(!check(pe_hip_load_circuit(h, 2, 1, count, 2, tabs), h, "load_circuit")) return false;
+        if(!check(pe_hip_load_circuit(h, 2, 1, count, 3, tabs), h, "load_circuit")) return false;
         pe_hip_run_stats st{};
         auto snap = [&]
         {
@@ -102,6 +120,18 @@ namespace
         };
         if(!check(pe_hip_analyze_dc(h, PE_HIP_MODE_DC, &st), h, "analyze_dc") || st.n_failed) return false;
         if(!snap()) return false;
+        {
+            // small-signal point at the operating point just solved: phasors [re(3) | im(3)] per instance
+            if(!check(pe_hip_analyze_ac(h, ac_omega, &st), h, "analyze_ac")) return false;
+            std::vector<double> re(static_cast<size_t>(3) * count), im(static_cast<size_t>(3) * count);
+            if(!check(pe_hip_get_solution_ac(h, 0, count, re.data(), im.data()), h, "get_solution_ac")) return false;
+            for(int b = 0; b < count; ++b)
+            {
+                phasors[first + b].assign(re.begin() + 3 * b, re.begin() + 3 * b + 3);
+                phasors[first + b].insert(phasors[first + b].end(), im.begin() + 3 * b, im.begin() + 3 * b + 3);
+            }
+            if(m.ac_events != count) { std::fprintf(stderr, "PE_HIP_OVERLAY_AC: %d calls for %d instances\n", m.ac_events, count); return false; }
+        }
         for(int s = 0; s < 6; ++s)
         {
             if(!check(pe_hip_analyze_tr(h, 1e-7, 1, &st), h, "analyze_tr") || st.n_failed) return false;
@@ -116,11 +146,11 @@ namespace
 int main()
 {
     std::vector<double> const r{1000.0, 1500.0, 700.0}, k{0.0, 2e-4, 8e-4};
-    std::vector<std::vector<double>> batched(3), single(3);
+    std::vector<std::vector<double>> batched(3), single(3), ph3(3), ph1(3);
     int ev3 = 0, ev1 = 0;
-    if(!run(0, 3, r, k, batched, ev3)) return 1;
+    if(!run(0, 3, r, k, batched, ev3, ph3)) return 1;
     for(int b = 0; b < 3; ++b)
-        if(!run(b, 1, r, k, single, ev1)) return 2;
+        if(!run(b, 1, r, k, single, ev1, ph1)) return 2;
     if(ev3 == 0 || ev1 != 0)
     {
         std::fprintf(stderr, "PE_HIP_OVERLAY_INSTANCE: %d events in the batch of 3 (expected some), %d with batch = 1 (expected none)\n", ev3, ev1);
@@ -144,6 +174,24 @@ int main()
             return 6;
         }
     }
+    // AC with host-stamped models on the batch: bit for bit the single runs, and the closed form v2 = I / (1/R + g + 3 k v^2 + j omega C)
+    for(int b = 0; b < 3; ++b)
+    {
+        if(ph3[b].size() != 6 || ph1[b].size() != 6) return 8;
+        if(std::memcmp(ph3[b].data(), ph1[b].data(), 6 * sizeof(double)) != 0)
+        {
+            std::fprintf(stderr, "instance %d AC phasor: batch (%.17g, %.17g), alone (%.17g, %.17g)\n", b, ph3[b][1], ph3[b][4], ph1[b][1], ph1[b][4]);
+            return 9;
+        }
+        double const v = batched[b][1], yr = 1.0 / r[b] + 1e-3 + 3.0 * k[b] * v * v + 1e-12, yi = ac_omega * 2e-9, den = yr * yr + yi * yi;
+        double const wre = ac_amp * yr / den, wim = -ac_amp * yi / den;
+        if(std::fabs(ph3[b][1] - wre) > 1e-9 * std::fabs(wre) + 1e-15 || std::fabs(ph3[b][4] - wim) > 1e-9 * std::fabs(wim) + 1e-15)
+        {
+            std::fprintf(stderr, "instance %d AC phasor (%.12g, %.12g), expected (%.12g, %.12g)\n", b, ph3[b][1], ph3[b][4], wre, wim);
+            return 10;
+        }
+    }
+    if(ph3[0][1] == ph3[1][1] || ph3[1][1] == ph3[2][1]) return 11;
     // the instances differ (the batch did not collapse onto instance 0)
     if(batched[0][1] == batched[1][1] || batched[1][1] == batched[2][1]) return 7;
     std::printf("overlay on a batch of 3 = three runs of one: bit for bit; v2 = %.9f %.9f %.9f V\n", batched[0][1], batched[1][1], batched[2][1]);

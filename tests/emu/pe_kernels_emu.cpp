@@ -210,13 +210,21 @@ namespace pe
     bool emu_factor_top(Team const& tm, DevView const& V, int b, double* mem)
     {
         bool ok = true;
-        for_each_top_launch(V, V.batch, V.high_occupancy && V.n_waves == 4, 512,
+        for_each_top_launch(V, V.batch, V.high_occupancy && V.n_waves == 4, V.mid_top_limit,
                             [&](TopLaunch const& t)
                             {
                                 ChainState cs;  // (a run of single-front wide levels is ONE workgroup on the device: k_m2_factor_top_wide)
                                 for(int l = t.level; l < t.level + t.nlev; ++l)
                                     for(int i = V.top_ptr[l]; i < V.top_ptr[l + 1]; ++i)
+                                    {
+                                        if(V.f_need[V.top_list[i]] > static_cast<int>(t.lds_doubles) - 2)  // the device's guard (pe_kernels.hip lds_overrun)
+                                        {
+                                            V.flags[b] |= 8;
+                                            ok = false;
+                                            continue;
+                                        }
                                         if(!front_factor<Team, true>(tm, V, b, V.top_list[i], mem, static_cast<int>(t.lds_doubles) - 2, 0, true, t.kind == 1 ? &cs : nullptr)) ok = false;
+                                    }
                             });
         return ok;
     }

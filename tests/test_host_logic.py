@@ -317,6 +317,38 @@ assert np.max(np.abs(eng2.solution()[0] - eng.solution()[0]) / (1e-9 + 1e-9 * np
     subprocess.run(["python3", "-c", code], check=True, timeout=900)
 
 
+def test_lds_guard_refuses_the_round3_grouping(emu_lib):
+    """Product-side LDS guard (reference contract: "return false, never corrupt", circuit.h:1517).  Knob TEST_OLD_TOP_RUNS re-enables the
+    round-3 grouping bug -- a run of single-front top levels joins levels of different LDS classes and takes the launch of its first
+    level -- under the population rule it occurred with (half-CU levels up to 1 280 workgroups, geometry of 1 024 instances): the front
+    118 x 40 (panel layout, 8 076 doubles) would land on a launch with 5 072.  The load must be refused with PE_HIP_ERR_INTERNAL at plan
+    time (upload_symbolic: check_lds_plan); with the knob off the same plan loads and solves.  The per-engine launch knobs (MID_TOP,
+    EW_GRID, QUAD_LDS) live in the engine's view: two engines of one process keep their own."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load()
+deck = pe.deck.rc_mesh(100, 100, 1, True)
+def engine(old):
+    eng = pe.ffi.Engine(); eng.set_knob('GEOMETRY_BATCH', 1024); eng.set_knob('TOP_HALF_WGS', 1280); eng.set_knob('TEST_OLD_TOP_RUNS', old)
+    eng.set_options(g_min=0.0)
+    return eng
+good = engine(0); good.load_deck(deck); good.reset()
+assert good.analyze_tr(1e-10, 1)['newton_iters'] == 2
+bad = engine(1)
+try:
+    bad.load_deck(deck); bad.reset(); bad.analyze_tr(1e-10, 1)
+    raise SystemExit('the mis-grouped launch plan was accepted')
+except pe.ffi.PeHipError as e:
+    assert e.code == pe.ffi.ERR_INTERNAL and 'needs 8076 doubles of LDS' in str(e) and 'has 5072' in str(e), str(e)
+# the good engine is untouched by the other engine's knobs and failure
+assert good.analyze_tr(1e-10, 1)['newton_iters'] >= 1
+"""
+    subprocess.run(["python3", "-c", code], check=True, timeout=900)
+
+
 def test_launch_plan_of_a_sweep_under_host_emulation(emu_lib, oracle_mod):
     """The top levels of the 10k-node mesh as a sweep of 128 / 512 / 1 024 instances runs them (knob GEOMETRY_BATCH: the geometry, the
     second analysis pass that forms the top fronts against the LDS of their launch, and the launch plan of pe_top_plan.hpp are those
@@ -471,6 +503,15 @@ c.set_knob('SPLIT', 1); c.set_knob('PARTS', 4)   # resident circuit: re-analysed
 c.analyze_tr(1e-10, 2); a.analyze_tr(1e-10, 2)
 assert c.info()['n_parts'] == 4
 assert np.max(np.abs(c.solution()[0] - a.solution()[0])) < 1e-9
+# the launch-shape knobs (round 3: function-local statics of the launcher, process-wide and frozen at first use) live in each engine's view
+os.environ['PHY_ENGINE_HIP_EW_GRID'] = '3'
+d = engine(SPLIT=1, MID_TOP=100, EW_GRID=7, QUAD_LDS=4096)
+e = engine(SPLIT=1)                               # (created later, environment changed since the first launch of the process)
+ia, id_, ie = a.info(), d.info(), e.info()
+assert (id_['mid_top_limit'], id_['ew_grid'], id_['quad_lds_pad']) == (100, 7, 4096), id_
+assert (ie['mid_top_limit'], ie['ew_grid'], ie['quad_lds_pad']) == (512, 3, 0), ie
+assert (ia['mid_top_limit'], ia['ew_grid'], ia['quad_lds_pad']) == (512, 0, 0), ia
+assert np.max(np.abs(d.solution()[0] - e.solution()[0])) < 1e-9
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
 
