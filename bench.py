@@ -253,6 +253,13 @@ def main():
             tdev = torch.device("cpu")
             dist.init_process_group(backend)
 
+    # the line reports n_gpus = the ranks that really joined: a launch that asked for --gpus N and got another world size is refused
+    # (a silent N = 1 run labelled n_gpus: 8 would be the worst kind of scaling number)
+    ranks_seen = dist.get_world_size() if dist is not None else 1
+    if ranks_seen != world or (args.gpus != ranks_seen and not os.environ.get("PE_BENCH_ALLOW_GPUS_MISMATCH")):
+        raise SystemExit(f"rank {rank}: --gpus {args.gpus} but {ranks_seen} rank(s) joined (WORLD_SIZE={world}): launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}")
+
     pe = pe_load.load()
     W = args.mesh
     nonlinear = not args.linear
@@ -301,10 +308,18 @@ def main():
         gpu_ms = st["gpu_ms"]
         steps_total, iters_total = float(st["steps"]), float(st["newton_iters"])
 
-    # the one exchange step of the sweep: per-node statistics at t_end
+    # the one exchange step of the sweep: per-node statistics at t_end (device kernel + 320 KB D2H), then the two packed all-reduces --
+    # timed separately: allreduce_ms is what RCCL over xGMI adds at N > 1 (0 on one rank)
     t1 = time.perf_counter()
-    stats = reduce_statistics(eng.sweep_statistics(), dist, tdev)
-    reduce_ms = (time.perf_counter() - t1) * 1e3
+    local_stats = eng.sweep_statistics()
+    t2 = time.perf_counter()
+    stats = reduce_statistics(local_stats, dist, tdev)
+    if dist is not None and tdev.type == "cuda":
+        import torch
+        torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    reduce_ms = (t3 - t1) * 1e3
+    allreduce_ms = (t3 - t2) * 1e3 if ranks_seen > 1 else 0.0
 
     if rank == 0:
         bpi = bytes_per_iteration(info)
@@ -347,7 +362,10 @@ def main():
             "metric": "transient steps/sec (+ Newton iters/sec), 10k-node RC mesh",
             "value": steps_total / el,
             "unit": "instance-steps/s",
-            "n_gpus": world,
+            "n_gpus": ranks_seen,
+            "ranks_seen": ranks_seen,
+            "collective_backend": (backend if dist is not None else None),
+            "build_id": pe.ffi.build_id(),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3,
@@ -373,6 +391,7 @@ def main():
                                         "gpu_ms": st["gpu_ms"], "schedule": "split: k_m2_eval/stamp/winit/factor_parts/factor_top x levels/"
                                         "solve_top x levels/backward_parts/finish per Newton iteration (stamp: x-dependent slots only after the first iteration of a time point)" if split else "resident k_tr_steps"}},
             "reduce_ms": reduce_ms,
+            "allreduce_ms": allreduce_ms,
             "stats_checksum": float(np.sum(stats[0])),
             "engine": dict({k: info[k] for k in ("n_fronts", "max_front", "tree_depth", "nnz_lu_stored", "factor_flops", "bytes_per_instance")},
                            stored_over_structural=info["nnz_lu_stored"] / max(1, info["nnz_lu"]), n_wave_fronts=info.get("n_wave_fronts"),
@@ -390,16 +409,25 @@ def main():
         # HBM bytes of the dominant kernel from the PMC counters: OFFLINE figure (rocprofv3 cannot profile the process that prints
         # this line) -- two separate --pmc passes of this same command, corrected with the factors calibrated on this engine's
         # access shapes (scripts/hbm_calib.hip); copied from the committed summary only when it was measured for this configuration
-        tp = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if os.path.exists(tp):
+        # ... and only when that summary was measured on THIS build of the library (pe_hip_build_id: hash of its sources and flags):
+        # a figure from another library is reported as stale, never silently carried over
+        for tp in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
             try:
-                tj = json.load(open(tp))
-                if tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W and \
-                        tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]:
-                    line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                    line["roofline"]["traffic_source"] = "offline: " + tj.get("note", "")
+                tj = json.load(open(os.path.join(ROOT, "profiles", tp)))
             except Exception:
-                pass
+                continue
+            if not (tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W and
+                    tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]):
+                continue
+            if tj.get("build_id") == line["build_id"]:
+                line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                line["roofline"]["traffic_over_algorithmic"] = tj["hbm_bytes_per_launch"] / (dom_bytes / dom_launches)
+                line["roofline"]["traffic_source"] = f"profiles/{tp} (build_id {tj['build_id']}): " + tj.get("note", "")
+                line["roofline"].pop("traffic_stale", None)
+                break
+            line["roofline"]["traffic_stale"] = True
+            line["roofline"].setdefault("traffic_source", f"none for build_id {line['build_id']}: newest summary profiles/{tp} is of build "
+                                                          f"{tj.get('build_id', 'unknown (before round 4)')} ({tj['hbm_bytes_per_launch']:.4g} B per launch there)")
         if world == 1 and not args.no_single:
             # extra (outside the timed region): ONE M10k circuit on the GPU -- the latency-bound case of config C3
             try:

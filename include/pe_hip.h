@@ -225,7 +225,11 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
  *                             as circult::solve does (circuit.h:950-963) -- return 0 to accept it, PE_HIP_OVERLAY_VETO to iterate again
  *                             (counts against max_newton like any other iteration); a_values / b_values NULL */
 #define PE_HIP_OVERLAY_CONVERGED 2
-#define PE_HIP_OVERLAY_VETO 2
+#define PE_HIP_OVERLAY_VETO 100 /* a RETURN value (of the CONVERGED event only), deliberately unlike every event number and every small error code */
+/* COMPATIBILITY NOTE for callbacks written against round 2 (events STEP / ITERATE only): since round 3 every callback of a non-linear
+ * circuit also receives PE_HIP_OVERLAY_CONVERGED, every callback of a batch > 1 PE_HIP_OVERLAY_INSTANCE -- both with a_values / b_values
+ * NULL -- and PE_HIP_OVERLAY_AC where small-signal analysis is used.  A callback must dispatch on `event` and return 0 for events it does
+ * not handle; one that treats "anything but STEP" as ITERATE would write through NULL. */
 /*     PE_HIP_OVERLAY_AC       one small-signal point of pe_hip_analyze_ac (the models' iterate_ac hooks, circuit.h:389-431): t carries
  *                             omega, x the operating point; a_values holds 2 n_cells doubles -- the real parts of the cells, then the
  *                             imaginary parts -- and b_values 2 n_rhs likewise */

@@ -83,6 +83,30 @@ namespace pe_eng PE_ENG_HIDDEN
         return PE_HIP_OK;
     }
 // device side of a load: uploads h->hc (topology, contribution lists, parameters) and allocates the per-instance state
+// The slots of the device value vector that are written at LOAD time only (1.0, g_min, conductances, DC sources, digital drives, the
+// static generator values) from the host circuit's CURRENT parameters -- also re-applied over a restored checkpoint, whose blob holds
+// the saver's copy of them (pe_hip_checkpoint_load: a parameter edited since, or a circuit built with other values, keeps its own).
+void fill_static_dv(pe_hip_engine const* h, std::vector<double>& dv)
+{
+    auto const& hc = h->hc;
+    size_t const B = static_cast<size_t>(hc.batch);
+    for(size_t b = 0; b < B; ++b)
+    {
+        double* d = &dv[b * hc.dv_len];
+        d[pe::DV_ONE] = 1.0;
+        d[pe::DV_GMIN] = h->opt.g_min;
+        for(int i = 0; i < hc.nR(); ++i) d[hc.dv_r + i] = hc.r_g[b * hc.nR() + i];
+        for(int i = 0; i < hc.nVdc(); ++i) d[hc.dv_vdc + i] = hc.vdc_v[b * hc.nVdc() + i];
+        for(int i = 0; i < hc.nIdc(); ++i) d[hc.dv_idc + i] = hc.idc_i[b * hc.nIdc() + i];
+        for(int k = 0; k < hc.n_drives; ++k) d[hc.dv_drv + k] = hc.drv_volt[k];
+        for(auto const& g: hc.gen)
+        {
+            double sv;
+            if(pe::gen_static_value(g.kind, &hc.gen_par[b * hc.gen_par_len + g.par], r_open_of(h), sv)) d[g.dv] = sv;
+        }
+    }
+}
+
 int finish_load(pe_hip_engine* h)
 {
     auto const& hc = h->hc;
@@ -174,21 +198,7 @@ int finish_load(pe_hip_engine* h)
     // static part of dv
     {
         std::vector<double> dv(B * hc.dv_len, 0.0);
-        for(size_t b = 0; b < B; ++b)
-        {
-            double* d = &dv[b * hc.dv_len];
-            d[pe::DV_ONE] = 1.0;
-            d[pe::DV_GMIN] = h->opt.g_min;
-            for(int i = 0; i < hc.nR(); ++i) d[hc.dv_r + i] = hc.r_g[b * hc.nR() + i];
-            for(int i = 0; i < hc.nVdc(); ++i) d[hc.dv_vdc + i] = hc.vdc_v[b * hc.nVdc() + i];
-            for(int i = 0; i < hc.nIdc(); ++i) d[hc.dv_idc + i] = hc.idc_i[b * hc.nIdc() + i];
-            for(int k = 0; k < hc.n_drives; ++k) d[hc.dv_drv + k] = hc.drv_volt[k];
-            for(auto const& g: hc.gen)
-            {
-                double sv;
-                if(pe::gen_static_value(g.kind, &hc.gen_par[b * hc.gen_par_len + g.par], r_open_of(h), sv)) d[g.dv] = sv;
-            }
-        }
+        fill_static_dv(h, dv);
         double* ddv{};
         HIPCHK(h, P.alloc(ddv, dv.size(), false));
         HIPCHK(h, hipMemcpy(ddv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -361,6 +371,7 @@ int pe_hip_set_digital_drives(pe_hip_engine* h, int count, const int* node, cons
                 std::vector<double> col(h->hc.batch, volt[k]);
                 HIPCHK(h, hipMemcpy2D(h->V.dv + h->hc.dv_drv + k, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double),
                                       h->hc.batch, hipMemcpyHostToDevice));
+                h->hc.drv_volt[k] = volt[k];  // (the host circuit mirrors the resident values: fill_static_dv)
             }
         }
         else

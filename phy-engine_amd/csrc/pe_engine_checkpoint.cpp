@@ -16,7 +16,36 @@ namespace
     {
         char magic[8];
         long long rows, batch, nC, nD, nRl, dv_len;
+        unsigned long long fingerprint;  // of the circuit's STRUCTURE in the order it was built (below): sizes alone cannot tell two
+                                         // circuits with the same counts but another node / device order apart
     };
+    // FNV-1a over the MNA pattern and the contribution lists of every matrix slot / right-hand-side row (which device value lands where,
+    // with which sign): equal for the same netlist built in the same order, different as soon as a node or a device changes place.
+    // Parameter VALUES are not part of it -- they are not taken from a blob (pe_hip_checkpoint_load re-applies the circuit's own).
+    unsigned long long structure_fingerprint(pe::HostCircuit const& hc)
+    {
+        unsigned long long f = 1469598103934665603ull;
+        auto mix = [&](void const* p, size_t n)
+        {
+            auto const* c = static_cast<unsigned char const*>(p);
+            for(size_t i = 0; i < n; ++i) f = (f ^ c[i]) * 1099511628211ull;
+        };
+        auto vec = [&](std::vector<int> const& v)
+        {
+            size_t const n = v.size();
+            mix(&n, sizeof(n));
+            if(n) mix(v.data(), n * sizeof(int));
+        };
+        long long const sizes[8] = {hc.rows, hc.n_nodes, hc.n_branches, hc.nC(), hc.nD(), hc.nRl(), hc.dv_len, hc.nonlinear};
+        mix(sizes, sizeof(sizes));
+        vec(hc.rp);
+        vec(hc.ci);
+        vec(hc.a_ptr);
+        vec(hc.a_src);
+        vec(hc.b_ptr);
+        vec(hc.b_src);
+        return f;
+    }
     struct CkPart
     {
         void* ptr;
@@ -61,7 +90,7 @@ int pe_hip_checkpoint_save(pe_hip_engine* h, void* buffer, size_t capacity)
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     auto const& hc = h->hc;
-    CkHeader hd{{'P', 'E', 'H', 'I', 'P', 'C', 'K', '1'}, hc.rows, hc.batch, hc.nC(), hc.nD(), hc.nRl(), hc.dv_len};
+    CkHeader hd{{'P', 'E', 'H', 'I', 'P', 'C', 'K', '2'}, hc.rows, hc.batch, hc.nC(), hc.nD(), hc.nRl(), hc.dv_len, structure_fingerprint(hc)};
     char* o = static_cast<char*>(buffer);
     std::memcpy(o, &hd, sizeof(hd));
     o += sizeof(hd);
@@ -80,15 +109,25 @@ int pe_hip_checkpoint_load(pe_hip_engine* h, const void* buffer, size_t size)
     auto const& hc = h->hc;
     CkHeader hd{};
     std::memcpy(&hd, buffer, sizeof(hd));
-    if(std::memcmp(hd.magic, "PEHIPCK1", 8) != 0 || hd.rows != hc.rows || hd.batch != hc.batch || hd.nC != hc.nC() || hd.nD != hc.nD() || hd.nRl != hc.nRl() ||
-       hd.dv_len != hc.dv_len)
-        return fail(h, PE_HIP_ERR_ARG, "checkpoint_load: the checkpoint belongs to a different circuit");
+    if(std::memcmp(hd.magic, "PEHIPCK2", 8) != 0 || hd.rows != hc.rows || hd.batch != hc.batch || hd.nC != hc.nC() || hd.nD != hc.nD() || hd.nRl != hc.nRl() ||
+       hd.dv_len != hc.dv_len || hd.fingerprint != structure_fingerprint(hc))
+        return fail(h, PE_HIP_ERR_ARG, "checkpoint_load: the checkpoint belongs to a different circuit (sizes or structure fingerprint: another topology, or the same one built in another order)");
     HIPCHK(h, hipSetDevice(h->device));
     char const* i = static_cast<char const*>(buffer) + sizeof(hd);
-    for(auto const& p: ck_parts(h))
+    auto const parts = ck_parts(h);
+    for(size_t k = 0; k + 1 < parts.size(); ++k)
     {
-        if(p.bytes) HIPCHK(h, hipMemcpy(p.ptr, i, p.bytes, hipMemcpyHostToDevice));
-        i += p.bytes;
+        if(parts[k].bytes) HIPCHK(h, hipMemcpy(parts[k].ptr, i, parts[k].bytes, hipMemcpyHostToDevice));
+        i += parts[k].bytes;
+    }
+    // the device value vector (last part): the x-dependent / companion slots come from the blob, the slots written at load time only
+    // (conductances, DC sources, g_min, ...) from THIS circuit's current parameters -- a blob must not revert a parameter edited since
+    // the save, nor impose the saver's values on a circuit built with others (round-3 advisor finding)
+    {
+        std::vector<double> dv(static_cast<size_t>(hc.batch) * hc.dv_len);
+        if(!dv.empty()) std::memcpy(dv.data(), i, dv.size() * sizeof(double));
+        fill_static_dv(h, dv);
+        if(!dv.empty()) HIPCHK(h, hipMemcpy(h->V.dv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     h->fact_valid = false;
     return PE_HIP_OK;

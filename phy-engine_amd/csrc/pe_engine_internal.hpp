@@ -194,6 +194,7 @@ namespace pe_eng PE_ENG_HIDDEN
     void apply_options(pe_hip_engine* h, pe::DevView& V);
     int stats_chunks(int batch);
     int finish_load(pe_hip_engine* h);
+    void fill_static_dv(pe_hip_engine const* h, std::vector<double>& dv);
     int collect_stats(pe_hip_engine* h, std::vector<long long> const& steps0, std::vector<long long> const& iters0, pe_hip_run_stats* st);
     int snapshot_counters(pe_hip_engine* h, std::vector<long long>& s0, std::vector<long long>& i0);
     // pe_engine_policy.cpp

@@ -175,7 +175,9 @@ namespace pe_eng PE_ENG_HIDDEN
         if(h->pub_host) (void)hipHostFree(h->pub_host);
         h->pub_host = h->pub_dev = nullptr;
         h->pub_cap = 0;
-        HIPCHK(h, hipHostMalloc(&h->pub_host, need, hipHostMallocDefault));
+        // (coherent + mapped, explicitly: the device's system-scope release of the sequence word must reach the polling host even where
+        //  HIP_HOST_COHERENT=0 makes default pinned allocations non-coherent)
+        HIPCHK(h, hipHostMalloc(&h->pub_host, need, hipHostMallocCoherent | hipHostMallocMapped));
         HIPCHK(h, hipHostGetDevicePointer(&h->pub_dev, h->pub_host, 0));
         std::memset(h->pub_host, 0, need);
         h->pub_cap = need;

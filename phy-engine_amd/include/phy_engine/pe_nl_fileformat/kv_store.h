@@ -72,7 +72,7 @@ namespace phy_engine::pe_nl_fileformat::kv
     }
     inline bool get_fixed32(std::string_view in, std::size_t off, std::uint32_t& v)
     {
-        if(off + 4 > in.size()) return false;
+        if(off > in.size() || in.size() - off < 4) return false;  // (overflow-free: `off` may come from a 64-bit length in the file)
         std::memcpy(&v, in.data() + off, 4);
         return true;
     }
@@ -125,7 +125,13 @@ namespace phy_engine::pe_nl_fileformat::kv
                 std::size_t const n = static_cast<unsigned char>(blk[off + 4]) | (static_cast<std::size_t>(static_cast<unsigned char>(blk[off + 5])) << 8);
                 int const type = static_cast<unsigned char>(blk[off + 6]);
                 if(type == 0 && n == 0 && stored == 0) break;  // zero fill (pre-allocated tail): nothing more in this block
-                if(off + log_header + n > blk.size()) return {errc::corrupt, std::string(what) + ": record fragment runs past its block"};
+                if(off + log_header + n > blk.size())
+                {
+                    // a fragment that runs past a SHORT last block is a torn tail (a writer that died mid-append): end of log, as LevelDB's
+                    // reader reports it (kEof, dropped silently); past a full 32 KiB block it is corruption
+                    if(base + log_block >= file.size() && blk.size() < log_block) return {};
+                    return {errc::corrupt, std::string(what) + ": record fragment runs past its block"};
+                }
                 char const tb = static_cast<char>(type);
                 std::uint32_t crc = crc32c(&tb, 1);
                 crc = crc32c(blk.data() + off + log_header, n, crc);
@@ -236,7 +242,9 @@ namespace phy_engine::pe_nl_fileformat::kv
     inline constexpr std::uint64_t table_magic = 0xdb4775248b80fb57ull;
     inline status table_block(std::string_view file, std::uint64_t offset, std::uint64_t size, std::string_view& contents, char const* what)
     {
-        if(offset > file.size() || size + 5 > file.size() - offset) return {errc::corrupt, std::string(what) + ": block handle out of range"};
+        // (overflow-free: offset and size are 64-bit varints from a footer / index entry no checksum protects -- size = 2^64 - 5 .. 2^64 - 1
+        //  wrapped `size + 5` and passed the check; ASan: heap-buffer-overflow read below)
+        if(offset > file.size() || size > file.size() - offset || file.size() - offset - size < 5) return {errc::corrupt, std::string(what) + ": block handle out of range"};
         std::string_view const raw = file.substr(static_cast<std::size_t>(offset), static_cast<std::size_t>(size) + 5);
         std::uint32_t stored{};
         get_fixed32(raw, static_cast<std::size_t>(size) + 1, stored);
@@ -257,7 +265,7 @@ namespace phy_engine::pe_nl_fileformat::kv
         for(std::size_t off = 0; off < end;)
         {
             std::uint64_t shared{}, fresh{}, vlen{};
-            if(!get_varint(blk, off, shared) || !get_varint(blk, off, fresh) || !get_varint(blk, off, vlen) || shared > key.size() || fresh + vlen > end - off)
+            if(!get_varint(blk, off, shared) || !get_varint(blk, off, fresh) || !get_varint(blk, off, vlen) || shared > key.size() || fresh > end - off || vlen > end - off - fresh)
                 return {errc::corrupt, std::string(what) + ": bad block entry"};
             key.resize(static_cast<std::size_t>(shared));
             key.append(blk.substr(off, static_cast<std::size_t>(fresh)));

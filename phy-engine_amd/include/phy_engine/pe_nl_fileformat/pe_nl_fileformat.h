@@ -582,6 +582,9 @@ namespace phy_engine::pe_nl_fileformat
         off = 0;
         if(auto st = read_uleb128(v, off, model_count); !st) return st;
 
+        // (counts come from the file: every node / model owns at least one key, so a count beyond the number of pairs is damage -- refused
+        //  before anything is sized by it; a status-returning API must not leave through length_error / bad_alloc)
+        if(node_count > db.kv.size() || model_count > db.kv.size()) return {errc::corrupt, "nodes/count or models/count exceeds the number of keys in the container"};
         std::vector<::phy_engine::model::node_t*> cur_nodes;
         std::vector<::phy_engine::model::model_base*> cur_models;
         std::vector<std::uint64_t> node_map(static_cast<std::size_t>(node_count)), model_map(static_cast<std::size_t>(model_count));
@@ -667,8 +670,17 @@ namespace phy_engine::pe_nl_fileformat
                 c.cuda_node_threshold = static_cast<std::size_t>(thr);
                 // (the device engine of this circuit is built by its next analyze(): nothing is `prepared` in a freshly loaded object)
                 c.has_prepare = false;
+                // The device-resident state (runtime/pe_hip_state) is laid out in the SAVER's row and device order: it is adopted only
+                // where that order is this circuit's -- a full rebuild from this container, or a checkpoint whose node / model mapping
+                // is the identity.  A checkpoint mapped by stable ids onto a circuit built in another order keeps the netlist state
+                // (mapped per node / model above) and restarts the companions; pe_hip_checkpoint_load verifies a structure
+                // fingerprint on top (a blob that slips through here is refused there) and never takes parameter values from a blob.
                 c.pending_device_state.clear();
-                if(auto s3 = db.get("runtime/pe_hip_state", v); s3) c.pending_device_state.assign(v);
+                bool identity = true;
+                for(std::uint64_t i = 0; i < node_count && identity; ++i) identity = node_map[i] == i;
+                for(std::uint64_t i = 0; i < model_count && identity; ++i) identity = model_map[i] == i;
+                if(identity)
+                    if(auto s3 = db.get("runtime/pe_hip_state", v); s3) c.pending_device_state.assign(v);
             }
 
         std::vector<::phy_engine::model::node_t*> id_to_node(static_cast<std::size_t>(node_count));

@@ -6,7 +6,7 @@ import numpy as np
 import pe_load
 pe = pe_load.load()
 W = int(os.environ.get("MESH", "100"))
-for nonlinear in (False, True):
+for nonlinear in ((True,) if os.environ.get("NLONLY") else (False, True)):
     for B in [int(x) for x in os.environ.get("BATCHES", "1,128").split(",")]:
         seeds = list(range(1, B + 1))
         deck, r, c = pe.deck.rc_mesh_params(W, W, seeds, nonlinear)

@@ -15,7 +15,7 @@ fetch_dir, write_dir, bench_json = sys.argv[1:4]
 line = json.loads(open(bench_json).read().strip().splitlines()[-1])
 kernel = sys.argv[4] if len(sys.argv) > 4 else line["roofline"]["kernel"].split("<")[0]
 kernels = [k.strip() for k in kernel.split("+")]
-TAG = os.environ.get("TAG", "r03")
+TAG = os.environ.get("TAG", "r04")
 
 
 def newest(d):
@@ -44,6 +44,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cal = json.load(open(os.path.join(root, "profiles", "r02_hbm_calib.json")))
 ff, wf = cal["fetch_factor_for_this_engine"], cal["write_factor_for_this_engine"]
 out = {
+    "build_id": line.get("build_id"),  # the library the passes ran (bench.py copies roofline.traffic only on a match with its own)
     "instances_per_gpu": line["config"]["instances_rank0"], "nonlinear": "-NL" in line["config"]["workload"], "mesh": 100,
     "kernel": kernel, "dispatches": nf, "FETCH_SIZE_KiB_per_launch": f / nf, "WRITE_SIZE_KiB_per_launch": w / nw,
     "fetch_factor": ff, "write_factor": wf,

@@ -9,6 +9,9 @@
 //   penl_tool dump <path> [lenient]                                       load <path> into an empty circuit, print a canonical dump
 //   penl_tool apply <checkpoint> [lenient]                                build the circuit (unsolved), apply a runtime-only checkpoint, dump
 //   penl_tool solve <path> [lenient]                                      load, analyze(), print the node voltages
+//   penl_tool save <path> full file tr_edit / penl_tool solve_edit <path>  as tr / solve, with R2 doubled (set_attribute) before the second
+//                                                                         five steps: a parameter edited after a load must survive the
+//                                                                         device-state blob the container carries
 //   penl_tool schema                                                      model name, pins and attributes of every model both builds register
 //
 // exit 0 = ok; 2 = the library reported an error (its code and message on stderr).
@@ -77,6 +80,23 @@ namespace
         place(nl, pm::comparator{}, {&a, &r, &d0}, u8"cmp");
         place(nl, pm::NOT{}, {&d0, &d1}, u8"inv");
         place(nl, pm::OUTPUT{}, {&d1}, u8"probe");
+    }
+
+    // doubles the resistance of the model named R2 through the plug-in API's set_attribute (attribute 0 of `resistance`)
+    bool edit_r2(::phy_engine::circult& c)
+    {
+        auto& nl{c.get_netlist()};
+        for(auto& chunk: nl.models)
+            for(auto* m = chunk.begin; m != chunk.curr; ++m)
+            {
+                if(m->type != pm::model_type::normal || m->ptr == nullptr) continue;
+                if(m->name.size() != 2 || m->name.data()[0] != u8'R' || m->name.data()[1] != u8'2') continue;
+                pm::variant v{m->ptr->get_attribute(0)};
+                if(v.type != pm::variant_type::d) return false;
+                v.d *= 2.0;
+                return m->ptr->set_attribute(0, v);
+            }
+        return false;
     }
 
     // one of every model both builds register, every attribute set THROUGH set_attribute to a value of its own (so that a unit
@@ -351,7 +371,8 @@ int main(int argc, char** argv)
         else
             build(c);
         bool solved = false;
-        bool const tr = argc > 5 && std::strcmp(argv[5], "tr") == 0;
+        bool const tr_edit = argc > 5 && std::strcmp(argv[5], "tr_edit") == 0;
+        bool const tr = tr_edit || (argc > 5 && std::strcmp(argv[5], "tr") == 0);
         if(tr)
         {
             // five transient steps, save, five more: the dump printed is the UNINTERRUPTED run's -- `solve <path>` (load, five steps)
@@ -377,6 +398,7 @@ int main(int argc, char** argv)
         if(int const rc = report(pf::save(path, c, o), "save"); rc) return rc;
         if(tr)
         {
+            if(tr_edit && !edit_r2(c)) return 4;
             if(!c.analyze()) return 3;
             c.digital_clk();
             solved = true;
@@ -384,11 +406,12 @@ int main(int argc, char** argv)
         dump(c, solved);
         return 0;
     }
-    if(cmd == "dump" || cmd == "solve")
+    if(cmd == "dump" || cmd == "solve" || cmd == "solve_edit")
     {
         ::phy_engine::circult c{};
         if(int const rc = report(pf::load(path, c, lopt(argc, argv, 3)), "load"); rc) return rc;
-        if(cmd == "solve")
+        if(cmd == "solve_edit" && !edit_r2(c)) return 4;
+        if(cmd == "solve" || cmd == "solve_edit")
         {
             if(!c.analyze())
             {

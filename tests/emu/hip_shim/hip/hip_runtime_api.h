@@ -23,7 +23,7 @@ inline hipError_t hipGetDeviceCount(int* n) { char const* v = std::getenv("PE_EM
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t b) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-constexpr unsigned hipHostMallocDefault = 0;
+constexpr unsigned hipHostMallocDefault = 0, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000;
 inline hipError_t hipHostMalloc(void** p, size_t b, unsigned) { *p = std::malloc(b ? b : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return hipSuccess; }

@@ -127,6 +127,89 @@ def test_transient_resumed_from_a_container_continues_bit_for_bit(tool, tmp_path
     assert run(tool, "solve", s).stdout != final
 
 
+def test_parameter_edited_after_a_load_survives_the_device_state_blob(tool, tmp_path):
+    """Round-3 advisor finding: the device-state blob of a container (runtime/pe_hip_state) holds the whole device value vector, the
+    slots written at load time included (conductances, DC sources, g_min).  Applied after load -> set_attribute it used to revert the
+    edit.  Now pe_hip_checkpoint_load re-applies THIS circuit's parameters over the blob: five steps, save, R2 doubled, five steps
+    (uninterrupted) = load, R2 doubled, five steps; and the edit matters (differs from the unedited continuation)."""
+    p = tmp_path / "tr_edit.penl"
+    final = run(tool, "save", p, "full", "file", "tr_edit").stdout
+    assert run(tool, "solve_edit", p).stdout == final
+    assert run(tool, "solve", p).stdout != final
+
+
+def footer_with_index_size(table: bytes, size: int) -> bytes:
+    """A sorted-table file with the index handle's SIZE in its footer replaced (footer = metaindex handle, index handle -- two varint64
+    pairs -- zero padding to 40 bytes, 8 bytes of magic; no checksum covers it)."""
+    def varint(b, i):
+        v = s = 0
+        while True:
+            c = b[i]
+            i += 1
+            v |= (c & 0x7F) << s
+            s += 7
+            if not c & 0x80:
+                return v, i
+
+    def enc(v):
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80)
+            v >>= 7
+        out.append(v)
+        return bytes(out)
+    foot = table[-48:]
+    mo, i = varint(foot, 0)
+    ms, i = varint(foot, i)
+    io, i = varint(foot, i)
+    _, i = varint(foot, i)
+    body = enc(mo) + enc(ms) + enc(io) + enc(size)
+    assert len(body) <= 40
+    return table[:-48] + body + bytes(40 - len(body)) + foot[40:]
+
+
+@pytest.fixture(scope="module")
+def sanitized_tool(tool):
+    """penl_tool built with AddressSanitizer + UBSan (the container reader is header-only: all of it is instrumented)."""
+    out = os.path.join(CPP, "_build_emu", "penl_tool_asan")
+    src = os.path.join(CPP, "penl_tool.cpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(tool)):
+        subprocess.run(["g++", "-std=c++23", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I" + os.path.join(ROOT, "phy-engine_amd", "include"),
+                        "-I" + os.path.join(ROOT, "include"), "-o", out, src, os.path.join(CPP, "_build_emu", "pe_dll_api.o"), "-L" + os.path.join(ROOT, "tests", "emu"),
+                        "-lpe_hip_emu", "-Wl,-rpath," + os.path.join(ROOT, "tests", "emu")], check=True, timeout=900)
+    return out
+
+
+def test_crafted_block_handles_and_counts_are_refused(sanitized_tool, tmp_path):
+    """Round-3 advisor findings on the container reader, under ASan + UBSan: (1) a table footer whose index handle has size 2^64 - 5 ..
+    2^64 - 1 used to wrap `size + 5` past the bounds check and read out of bounds (LevelDB footers carry no checksum: the 650 random
+    mutations could not reach it); (2) a log whose last block is torn mid-fragment is end-of-log, as LevelDB reports it, not
+    corruption.  Every crafted file must come back as an ERROR (exit 2) or load -- never a sanitizer report, never a crash."""
+    env_ok = (0, 2)
+    src = os.path.join(GOLD, "ref_reopened")
+    tables = [n for n in os.listdir(src) if n.endswith(".ldb") or n.endswith(".sst")]
+    assert tables, "the reopened fixture holds a sorted table"
+    for size in [2 ** 64 - k for k in range(1, 6)] + [2 ** 63, 2 ** 32 + 7, 0]:
+        d = tmp_path / "crafted"
+        shutil.rmtree(d, ignore_errors=True)
+        shutil.copytree(src, d)
+        t = d / tables[0]
+        t.write_bytes(footer_with_index_size(t.read_bytes(), size))
+        r = run(sanitized_tool, "dump", d, ok=False)
+        assert r.returncode in env_ok and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (size, r.returncode, r.stderr[-400:])
+        if size >= 2 ** 32:
+            assert r.returncode == 2 and "out of range" in r.stderr, (size, r.stderr[-300:])
+    # torn tail: the log of a database directory cut inside its last fragment
+    d = tmp_path / "torn"
+    shutil.copytree(os.path.join(GOLD, "ref_dir"), d)
+    logs = [n for n in os.listdir(d) if n.endswith(".log")]
+    assert logs
+    b = (d / logs[0]).read_bytes()
+    (d / logs[0]).write_bytes(b[:len(b) - 5])
+    r = run(sanitized_tool, "dump", d, ok=False)
+    assert r.returncode in env_ok and "Sanitizer" not in r.stderr and "runs past its block" not in r.stderr, (r.returncode, r.stderr[-400:])
+
+
 def test_existing_file_is_not_overwritten_silently_and_damage_is_detected(tool, tmp_path):
     p = tmp_path / "c.penl"
     run(tool, "save", p, "structure", "file")

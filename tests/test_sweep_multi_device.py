@@ -75,6 +75,12 @@ def test_bench_world2_gloo_statistics_equal_world1(emu):
     assert r2.returncode == 0, r2.stderr[-2000:]
     l2 = json.loads([l for l in r2.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert l1["n_gpus"] == 1 and l2["n_gpus"] == 2 and l2["scaling"] == "strong"
+    # the line reports the ranks that really joined, names the build of the library, and times the exchange step's all-reduce on its own
+    assert l1["ranks_seen"] == 1 and l2["ranks_seen"] == 2 and l2["collective_backend"] == "gloo" and l1["allreduce_ms"] == 0.0 and l2["allreduce_ms"] > 0.0
+    assert l1["build_id"] == l2["build_id"] and l1["build_id"]
+    # --gpus N without N ranks is refused instead of printing a mislabelled line
+    r3 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert r3.returncode != 0 and "rank(s) joined" in r3.stderr and not [l for l in r3.stdout.splitlines() if l.startswith("{")]
     assert l2["config"]["instances_total"] == 6 and l2["config"]["instances_rank0"] == 3
     assert l1["newton_iters_per_step"] == pytest.approx(l2["newton_iters_per_step"])
     assert l2["stats_checksum"] == pytest.approx(l1["stats_checksum"], rel=1e-12)
