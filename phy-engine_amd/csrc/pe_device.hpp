@@ -118,6 +118,10 @@ namespace pe
         double* zero;  // one 0.0 in device memory: where the masked-out lanes of an unconditional gather point
         long long const *f_lptr, *f_uptr, *f_sptr;
         int const *row_src, *col_src;
+        // split schedule, round 4: the stamp kernel also initialises the permuted work vector (w[k] = rhs[row_src[k]], what k_m2_winit did in
+        // a launch of its own): row_dst = inverse of row_src; row_dyn[r] != 0: row r is re-gathered by the x-dependent-only stamp (dyn_b)
+        int const* row_dst{};
+        unsigned char const* row_dyn{};
         // schedule (pe_symbolic.cpp): phase 1 = per-wavefront lists of small fronts, phase 2 = cooperative fronts
         // part q, wavefront w: wave_list[wave_ptr[q*(n_waves+1)+w] ..); cooperative fronts of part q: coop_list[coop_ptr[q] ..);
         // top fronts of level l: top_list[top_ptr[l] ..)  (multi-workgroup mode only)

@@ -279,7 +279,9 @@ namespace pe_eng PE_ENG_HIDDEN
     }
 
     // one solve point of every instance whose status is OK; result[b] = iterations (> 0) or a negative status
-    int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, bool do_factor, std::vector<int>& result, int& launches)
+    // companion_dt != null: a transient step -- its companion update rides in the first iteration's evaluation launch (k_m2_eval)
+    int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, bool do_factor, std::vector<int>& result, int& launches,
+                 double const* companion_dt = nullptr)
     {
         int const B = h->hc.batch;
         result.assign(B, 0);
@@ -297,7 +299,8 @@ namespace pe_eng PE_ENG_HIDDEN
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             // (test knob PHY_ENGINE_HIP_FULL_STAMP=1: every iteration stamps everything -- the x-dependent-only path must match it bit for bit)
             static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0 && !full_stamp));
+            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0 && !full_stamp,
+                                              /*companion=*/it == 0 && companion_dt != nullptr, companion_dt ? *companion_dt : 0.0));
             ++launches;
             // flags + residual norms of this iteration: published into pinned host memory by the iteration's last launch and polled
             // (no copy command, no stream synchronisation); PHY_ENGINE_HIP_PUBLISH=0: the copy + synchronise of rounds 1-2
@@ -398,7 +401,11 @@ namespace pe_eng PE_ENG_HIDDEN
             if(has_overlay(h) && !(skip_first && s == 0))
                 if(int const orc = overlay_call_all(h, PE_HIP_OVERLAY_STEP, PE_HIP_MODE_TR, S.t[0], dt, &S.active); orc != PE_HIP_OK) return orc;
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
-            if(!(skip_first && s == 0)) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
+            // (the companion update of this step runs inside the first iteration's evaluation launch: m2_point / k_m2_eval -- one launch
+            //  less per step; knob COMPANION_LAUNCH=1 keeps it a launch of its own)
+            bool const with_companion = !(skip_first && s == 0);
+            static bool const own_launch = env_int0("PHY_ENGINE_HIP_COMPANION_LAUNCH", 0) != 0;
+            if(with_companion && own_launch) HIPCHK(h, pe::launch_m2_companion(h->stream, h->V, dt));
             // every live instance sits at the same time point (same dt, lockstep); take it from the first live one
             double t_prev = 0.0;
             for(int b = 0; b < B; ++b)
@@ -410,7 +417,7 @@ namespace pe_eng PE_ENG_HIDDEN
             double const t = t_prev + dt;
             // linear circuit, same dt as the last factorisation: stamp + triangular solves only
             bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
-            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, !reuse, res, launches);
+            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, !reuse, res, launches, (with_companion && !own_launch) ? &dt : nullptr);
             if(rc != PE_HIP_OK) return rc;
             if(may_reuse)
             {

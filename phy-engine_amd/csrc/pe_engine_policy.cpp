@@ -96,6 +96,12 @@ namespace pe_eng PE_ENG_HIDDEN
         HIPCHK(h, pool.upload(V.f_uptr, S.f_uptr));
         HIPCHK(h, pool.upload(V.f_sptr, S.f_sptr));
         HIPCHK(h, pool.upload(V.row_src, S.row_src));
+        {
+            std::vector<int> dst(S.row_src.size(), 0);
+            for(size_t k = 0; k < S.row_src.size(); ++k) dst[static_cast<size_t>(S.row_src[k])] = static_cast<int>(k);
+            HIPCHK(h, pool.upload(V.row_dst, dst));
+            V.row_dyn = nullptr;  // (set with the x-dependent row list of the resident circuit, ensure_symbolic)
+        }
         HIPCHK(h, pool.upload(V.col_src, S.col_src));
         HIPCHK(h, pool.upload(V.wave_ptr, S.wave_ptr));
         HIPCHK(h, pool.upload(V.wave_list, S.wave_list));
@@ -569,6 +575,9 @@ namespace pe_eng PE_ENG_HIDDEN
                 if(db.empty()) db.push_back(0);
                 HIPCHK(h, h->sym_pool.upload(h->V.dyn_a, da));
                 HIPCHK(h, h->sym_pool.upload(h->V.dyn_b, db));
+                std::vector<unsigned char> rd(static_cast<size_t>(std::max(1, hc.rows)), 0);
+                for(int k = 0; k < h->V.n_dyn_b; ++k) rd[static_cast<size_t>(db[static_cast<size_t>(k)])] = 1;
+                HIPCHK(h, h->sym_pool.upload(h->V.row_dyn, rd));
             }
             h->V.asm_slot = nullptr;  // identity (pe_front.hpp front_factor); the solve_csr_real seam keeps CSR order + the map
             std::vector<int> slot_e(nnz, 0);  // CSR slot -> position in aval (residual check walks A row by row in original order)

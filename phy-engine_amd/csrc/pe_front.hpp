@@ -407,8 +407,10 @@ namespace pe
     // dependent loads ptr -> src -> dv of one slot would otherwise be fully exposed)
     // (t0, T): this thread's index and the thread count of the group that shares the slot range [lo, hi)
     // `list` != null: the slots are list[lo .. n) instead of lo .. n
+    // `out2` != null: the sum also goes to out2[perm[slot]] (the stamp kernel of the split schedule initialises the permuted work vector w)
     template <int UN = 4>
-    PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n, int const* list = nullptr)
+    PE_DEV void gather_contributions(int t0, int T, int const* ptr, int const* src, double const* dv, double* out, int lo, int n, int const* list = nullptr,
+                                     double* out2 = nullptr, int const* perm = nullptr)
     {
         for(int base = lo + t0; base < n; base += UN * T)
         {
@@ -447,7 +449,11 @@ namespace pe
             }
 #pragma unroll
             for(int q = 0; q < UN; ++q)
-                if(base + q * T < n) out[slot[q]] = acc[q];
+                if(base + q * T < n)
+                {
+                    out[slot[q]] = acc[q];
+                    if(out2) out2[perm[slot[q]]] = acc[q];
+                }
         }
     }
 
@@ -463,9 +469,12 @@ namespace pe
     // few enough to stay in the CU's L1: a 64-byte sector of dv is fetched from L2 once per chunk instead of once per lane.
     // Newton iterations after the first of a solve point: only the slots an x-dependent device contributes to are gathered again
     // (same lists, same summation order: bit-identical to a full stamp); everything else still holds the first iteration's values.
-    PE_DEV void stamp_dynamic_chunk(DevView const& V, int b, int g, int G, int t0, int T)
+    // with_w (split schedule): w = P rhs as well -- every gathered row writes its own entry of w, the rows the dynamic stamp does not
+    // gather are copied from the rhs of the first iteration (no thread reads what another one writes: no barrier, one launch less)
+    PE_DEV void stamp_dynamic_chunk(DevView const& V, int b, int g, int G, int t0, int T, bool with_w = false)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
+        double* w = with_w ? V.w + static_cast<long long>(b) * V.rows : nullptr;
         auto range = [&](int n, int& lo, int& hi)
         {
             int const c = (n + G - 1) / G;
@@ -476,11 +485,22 @@ namespace pe
         range(V.n_dyn_a, lo, hi);
         gather_contributions<PE_STAMP_UN>(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi, V.dyn_a);
         range(V.n_dyn_b, lo, hi);
-        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b, w, V.row_dst);
+        if(with_w)
+        {
+            double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
+            range(V.rows, lo, hi);
+            for(int k = lo + t0; k < hi; k += T)
+            {
+                int const r = V.row_src[k];
+                if(!V.row_dyn[r]) w[k] = rhs[r];
+            }
+        }
     }
-    PE_DEV void stamp_chunk(DevView const& V, int b, int g, int G, int t0, int T)
+    PE_DEV void stamp_chunk(DevView const& V, int b, int g, int G, int t0, int T, bool with_w = false)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
+        double* w = with_w ? V.w + static_cast<long long>(b) * V.rows : nullptr;
         auto range = [&](int n, int& lo, int& hi)
         {
             int const c = (n + G - 1) / G;
@@ -491,7 +511,7 @@ namespace pe
         range(V.nnzA, lo, hi);
         gather_contributions<PE_STAMP_UN>(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi);
         range(V.rows, lo, hi);
-        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi);
+        gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, nullptr, w, V.row_dst);
     }
 
     // ================================================================================================

@@ -622,11 +622,15 @@ namespace pe
         companion_update(GridTeam{}, V, b, dt);
     }
 
-    __global__ void __launch_bounds__(256) k_m2_eval(DevView V, int mode, double t, double last_step, int dynamic_only)
+    // companion_dt_set != 0: first Newton iteration of a transient step -- the trapezoidal companion update of that step (what k_m2_companion
+    // does in a launch of its own) runs first, in the same threads: companion_update and eval_devices deal out every device kind by the same
+    // thread index, so what eval reads of a device (history, junction voltage) is what THIS thread has just written; no barrier, one launch less
+    __global__ void __launch_bounds__(256) k_m2_eval(DevView V, int mode, double t, double last_step, int dynamic_only, int companion_dt_set, double companion_dt)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
         GridTeam tm;
+        if(companion_dt_set) companion_update(tm, V, b, companion_dt);
         double const* x = V.x + static_cast<long long>(b) * V.rows;
         double* xp = V.xprev + static_cast<long long>(b) * V.rows;
         for(int r = tm.tid(); r < V.rows; r += tm.size()) xp[r] = x[r];
@@ -639,13 +643,14 @@ namespace pe
         }
     }
 
+    // (also initialises the permuted work vector w = P rhs: k_m2_winit remains for the refinement solve, whose right-hand side is a residual)
     __global__ void __launch_bounds__(256) k_m2_stamp(DevView V, int dynamic_only)
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
-        if(dynamic_only) stamp_dynamic_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+        if(dynamic_only) stamp_dynamic_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), true);
         else
-        stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x));
+            stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), true);
     }
 
     // LDS guard of the top launches: front s laid out for more LDS than this launch has (V.f_need: image or panels + right-hand-side
@@ -1096,7 +1101,7 @@ namespace pe
     // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
     template <int MINW>
     static hipError_t m2_sequence(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1, bool refine,
-                                  bool stamp_dynamic = false)
+                                  bool stamp_dynamic = false, bool companion = false, double companion_dt = 0.0)
     {
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
@@ -1125,11 +1130,11 @@ namespace pe
         };
         if(!refine)
         {
-            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);
-            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);
+            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0, companion ? 1 : 0, companion_dt);
+            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);  // (+ w = P rhs)
         }
-        // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)
-        hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
+        else  // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)
+            hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
         if(do_factor)
         {
             // the factorisation carries the right-hand side along (fused forward substitution): no forward launches
@@ -1199,10 +1204,10 @@ namespace pe
     }
 
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1,
-                                   bool stamp_dynamic)
+                                   bool stamp_dynamic, bool companion, double companion_dt)
     {
-        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic)
-                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic);
+        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic, companion, companion_dt)
+                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic, companion, companion_dt);
     }
 
     // One round of iterative refinement of the active instances' last solve (same matrix values, same pivot order):

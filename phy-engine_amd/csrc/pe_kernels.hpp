@@ -18,8 +18,9 @@ namespace pe
     // multi-workgroup mode (V.n_parts > 1)
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt);
     // stamp_dynamic: not the first Newton iteration of this solve point -- only the x-dependent slots are stamped again (V.dyn_a / dyn_b)
+    // companion: first iteration of a transient step -- the companion update of that step (dt = companion_dt) runs inside the evaluation launch
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0 = nullptr,
-                                   hipEvent_t ev1 = nullptr, bool stamp_dynamic = false);
+                                   hipEvent_t ev1 = nullptr, bool stamp_dynamic = false, bool companion = false, double companion_dt = 0.0);
     // device-to-device stream copy of `bytes` (multiple of 16): the kernel behind pe_hip_measure_hbm_ceiling
     hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes);
     // one round of iterative refinement of the active instances' last solve + re-check (residual safety net, pe_front.hpp)

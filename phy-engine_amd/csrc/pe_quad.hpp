@@ -832,6 +832,9 @@ namespace pe
     // front_backward_lean + tri_upper on a 64-lane team (four interleaved partial sums of U12 x_anc, subtracted in order; the
     // refined quotient of the triangular solve): the results are those of the per-instance path.
     // =====================================================================================================================
+#ifndef PE_QUAD_BACK_DPP
+    #define PE_QUAD_BACK_DPP 1  // 0: round 3's one load per ancestor term (A/B switch)
+#endif
     template <class X>
     PEQ_DEV void quad_backward_list(DevView const& V, int quad, int list)
     {
@@ -894,11 +897,35 @@ namespace pe
                     for(int k = K; k < K + 4; ++k) ucol[k] = vd(0.0);
                 }
             }
+#if PE_QUAD_BACK_DPP
+            // positions of the ancestors' unknowns this lane fetches: x_anc[r] and x_anc[16 + r] (static table: requested with the panels)
+            vu const ia0 = X::to_u(X::ld_i32(blk + 8, X::to_u(X::sel(r < u, r, vi(0))) << 2)) << 3;
+            vu const ia1 = X::to_u(X::ld_i32(blk + 8, X::to_u(X::sel(r + 16 < u, r + 16, vi(0))) << 2)) << 3;
+#endif
             // the unknowns this front reads are in memory: behind a fence only if this wavefront wrote one of them since its last fence
             // (blk[6], pe_symbolic.cpp) -- else the loads above and below go out together, one memory round trip instead of two
             if(blk[6] || !PE_QUAD_BACK_LAZY_FENCE) X::fence();
             vd const wi = X::ld(baseW, offW + static_cast<unsigned>(c0) * 8u + ro);
             vd acc[4] = {vd(0.0), vd(0.0), vd(0.0), vd(0.0)};
+#if PE_QUAD_BACK_DPP
+            // x_anc: TWO loads per lane (lane r of an instance takes x_anc[r] and x_anc[16 + r]) and a row broadcast per term, instead of
+            // one load per term in which the 16 lanes of an instance read the same address -- 32 of the 81 vector memory instructions of
+            // a front; the kernel was bound by the address unit (round 4).  Same products, same order of the four partial sums.
+            vd const xlo = X::ld(baseW, offW + ia0), xhi = u > 16 ? X::ld(baseW, offW + ia1) : vd(0.0);
+#pragma unroll
+            for(int J = 0; J < 32; J += 4)
+            {
+                if(J < u)
+                {
+#pragma unroll
+                    for(int j = J; j < J + 4; ++j)
+                    {
+                        vd const xa = X::bcast(j < 16 ? xlo : xhi, j & 15);
+                        if(j < u) acc[j & 3] = acc[j & 3] + u12[j] * xa;
+                    }
+                }
+            }
+#else
 #pragma unroll
             for(int J = 0; J < 32; J += 4)
             {
@@ -913,6 +940,7 @@ namespace pe
                     }
                 }
             }
+#endif
             vd ti = wi;
 #pragma unroll
             for(int g = 0; g < 4; ++g) ti = ti - acc[g];

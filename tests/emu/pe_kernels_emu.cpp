@@ -246,7 +246,8 @@ namespace pe
             if(V.active[b]) companion_update(SerialTeam{1}, V, b, dt);
         return hipSuccess;
     }
-    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, bool stamp_dynamic)
+    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, bool stamp_dynamic,
+                                   bool companion, double companion_dt)
     {
         std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         SerialTeam tm{V.n_waves};
@@ -257,15 +258,22 @@ namespace pe
             double* xp = V.xprev + static_cast<long long>(b) * V.rows;
             double* w = V.w + static_cast<long long>(b) * V.rows;
             double const* rhs = V.rhs + static_cast<long long>(b) * V.rows;
+            if(companion) companion_update(SerialTeam{1}, V, b, companion_dt);  // (k_m2_eval: the step's companion update rides along)
             for(int r = 0; r < V.rows; ++r) xp[r] = x[r];
             eval_devices(tm, V, b, mode, t, last_step, stamp_dynamic && V.dyn_a && V.dyn_b);
             V.flags[b] = 0;
             if(V.eta_acc)
                 for(int k = 0; k < 4; ++k) V.eta_acc[4 * b + k] = 0.0;
-            if(stamp_dynamic && V.dyn_a && V.dyn_b) stamp_dynamic_chunk(V, b, 0, 1, 0, 1);
-            else
-                stamp(tm, V, b);
-            for(int k = 0; k < V.rows; ++k) w[k] = rhs[V.row_src[k]];
+            // (k_m2_stamp as the device runs it: the gathered rows write their entry of w, the others are copied -- in three chunks, like a
+            //  grid of three workgroups, so that the chunk arithmetic is exercised)
+            for(int k = 0; k < V.rows; ++k) w[k] = std::nan("");
+            for(int g = 0; g < 3; ++g)
+            {
+                if(stamp_dynamic && V.dyn_a && V.dyn_b) stamp_dynamic_chunk(V, b, g, 3, 0, 1, true);
+                else
+                    stamp_chunk(V, b, g, 3, 0, 1, true);
+            }
+            (void)rhs;
         }
         if(do_factor) emu_factor_quads(V);  // (a launch of its own on the device, between the stamp and the per-instance parts)
         for(int b = 0; b < V.batch; ++b)
