@@ -1,1 +1,1 @@
-#define PE_BUILD_ID "9bc939e024230b90"
+#define PE_BUILD_ID "6afc8e02b2fce425"

@@ -264,6 +264,7 @@ void pe_hip_destroy(pe_hip_engine* h)
     if(h->ac.d_worst) (void)hipFree(h->ac.d_worst);
     if(h->ac.eng) pe_hip_destroy(h->ac.eng);
     (void)hipStreamSynchronize(h->stream);
+    if(h->graphs) pe::m2_graphs_destroy(h->graphs);  // (captured launch sequences: before the memory they point into and their stream go)
     h->circ_pool.release();
     h->sym_pool.release();
     h->csr.pool.release();
@@ -389,6 +390,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->loaded = false;
     h->sym_class = -1;
     h->fact_valid = false;
+    pe::m2_graphs_clear(h->graphs);  // (captured launch sequences point into the circuit being replaced)
     h->circ_pool.release();
     h->stats_scratch = nullptr;
     h->stats_doubles = 0;

@@ -116,6 +116,9 @@ struct pe_hip_engine
     size_t pub_cap{};
     unsigned long long pub_seq{};
     std::vector<int> active_dev;
+    // captured launch sequences of the split schedule's Newton iteration (small sweeps; pe_kernels.hip launch_m2_iteration_graph)
+    pe::M2GraphCache* graphs{};
+    bool graph_mode{};            // the quad list behind the device's `active` mask is laid out for a captured sequence (full grid)
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
     size_t stats_doubles{};
     Pool circ_pool;  // topology, params, state

@@ -137,6 +137,11 @@ namespace pe_eng PE_ENG_HIDDEN
                 ql[4 * (nq - 1) + cnt++] = static_cast<int>(b);
             }
             for(; cnt > 0 && cnt < 4; ++cnt) ql[4 * (nq - 1) + cnt] = -1;
+            // captured launch sequences (m2_point: graph mode) keep ONE grid: the quads of the full sweep, the ones behind the active
+            // instances empty (the lane-group kernels return on a first member < 0)
+            if(h->graph_mode)
+                for(int const nq_all = static_cast<int>((B + 3) / 4); nq < nq_all; ++nq)
+                    for(int c = 0; c < 4; ++c) ql[4 * nq + c] = -1;
             h->V.n_quads = nq;
             h->V.q_list = h->V.active + B;
             words = B + 4 * static_cast<size_t>(nq);
@@ -183,14 +188,12 @@ namespace pe_eng PE_ENG_HIDDEN
         h->pub_cap = need;
         return PE_HIP_OK;
     }
-    // launches the publication of the iteration just enqueued and waits for it; `eta` (4 doubles per instance) may be null
-    int publish_and_wait(pe_hip_engine* h, std::vector<int>& flags, std::vector<double>* eta)
+    // waits for the publication with sequence number `seq` (launched by the caller: launch_m2_publish, or the last node of a captured
+    // iteration); `eta` (4 doubles per instance) may be null
+    int wait_published(pe_hip_engine* h, std::vector<int>& flags, std::vector<double>* eta, unsigned long long seq)
     {
         size_t const B = flags.size();
-        if(int const rc = ensure_published(h, B); rc != PE_HIP_OK) return rc;
-        auto const host = pub_view(h->pub_host, B), dev = pub_view(h->pub_dev, B);
-        unsigned long long const seq = ++h->pub_seq;
-        HIPCHK(h, pe::launch_m2_publish(h->stream, h->V, dev.flags, dev.eta, dev.seq, seq));
+        auto const host = pub_view(h->pub_host, B);
         for(unsigned spins = 0; __atomic_load_n(host.seq, __ATOMIC_ACQUIRE) != seq; ++spins)
         {
             if((spins & 1023u) == 1023u)
@@ -208,6 +211,16 @@ namespace pe_eng PE_ENG_HIDDEN
         std::copy(host.flags, host.flags + B, flags.begin());
         if(eta && h->V.residual_tol > 0.0) eta->assign(host.eta, host.eta + 4 * B);
         return PE_HIP_OK;
+    }
+    // launches the publication of the iteration just enqueued and waits for it
+    int publish_and_wait(pe_hip_engine* h, std::vector<int>& flags, std::vector<double>* eta)
+    {
+        size_t const B = flags.size();
+        if(int const rc = ensure_published(h, B); rc != PE_HIP_OK) return rc;
+        auto const dev = pub_view(h->pub_dev, B);
+        unsigned long long const seq = ++h->pub_seq;
+        HIPCHK(h, pe::launch_m2_publish(h->stream, h->V, dev.flags, dev.eta, dev.seq, seq));
+        return wait_published(h, flags, eta, seq);
     }
 
     // Residual safety net on the host-driven schedule.  The iteration just launched left the four norms of every active instance's
@@ -292,6 +305,19 @@ namespace pe_eng PE_ENG_HIDDEN
             n_active += S.active[b];
         }
         int const max_it = h->hc.nonlinear ? h->V.max_newton : 1;
+        // Small sweeps replay a captured launch sequence per iteration (pe_kernels.hip launch_m2_iteration_graph): the 15-20 launches of an
+        // iteration cost more host time than some of them run.  Large sweeps keep the plain launches -- their iteration is milliseconds,
+        // and the HIP events around the dominant pair (bench.py's roofline) live there.  Knob GRAPH = 0 / 1 forces either.
+        static bool const use_publish = env_int0("PHY_ENGINE_HIP_PUBLISH", 1) != 0;
+        // (measured, profiles/r04_ab_runs.log: -3.3 % per iteration for the single circuit, -0.8 % at 16 instances, nothing from 128 on --
+        //  there the kernels are long enough for the host to stay ahead of the stream)
+        bool const graph_mode = use_publish && knob(h, "GRAPH", B <= 32 ? 1 : 0) != 0;
+        if(graph_mode != h->graph_mode)
+        {
+            h->graph_mode = graph_mode;
+            h->active_dev.clear();  // (the quad list behind the mask is laid out differently)
+        }
+        if(graph_mode && !h->graphs) h->graphs = pe::m2_graphs_create();
         for(int it = 0; it < max_it && n_active > 0; ++it)
         {
             if(has_overlay(h))
@@ -299,20 +325,31 @@ namespace pe_eng PE_ENG_HIDDEN
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             // (test knob PHY_ENGINE_HIP_FULL_STAMP=1: every iteration stamps everything -- the x-dependent-only path must match it bit for bit)
             static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
-            HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/it > 0 && !full_stamp,
-                                              /*companion=*/it == 0 && companion_dt != nullptr, companion_dt ? *companion_dt : 0.0));
-            ++launches;
-            // flags + residual norms of this iteration: published into pinned host memory by the iteration's last launch and polled
-            // (no copy command, no stream synchronisation); PHY_ENGINE_HIP_PUBLISH=0: the copy + synchronise of rounds 1-2
-            static bool const use_publish = env_int0("PHY_ENGINE_HIP_PUBLISH", 1) != 0;
+            bool const dyn = it > 0 && !full_stamp, comp = it == 0 && companion_dt != nullptr;
             std::vector<double> eta_now;
-            if(use_publish)
+            if(graph_mode)
             {
-                if(int const prc = publish_and_wait(h, S.flags, &eta_now); prc != PE_HIP_OK) return prc;
+                if(int const prc = ensure_published(h, static_cast<size_t>(B)); prc != PE_HIP_OK) return prc;
+                auto const dev = pub_view(h->pub_dev, static_cast<size_t>(B));
+                unsigned long long const seq = ++h->pub_seq;
+                HIPCHK(h, pe::launch_m2_iteration_graph(h->stream, h->graphs, h->V, mode, t, last_step, do_factor, dyn, comp, companion_dt ? *companion_dt : 0.0, dev.flags,
+                                                        dev.eta, dev.seq, seq));
+                ++launches;
+                if(int const prc = wait_published(h, S.flags, &eta_now, seq); prc != PE_HIP_OK) return prc;
             }
-            else if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK)
-                return drc;  // (synchronises the stream)
+            else
             {
+                HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/dyn, /*companion=*/comp,
+                                                  companion_dt ? *companion_dt : 0.0));
+                ++launches;
+                // flags + residual norms of this iteration: published into pinned host memory by the iteration's last launch and polled
+                // (no copy command, no stream synchronisation); PHY_ENGINE_HIP_PUBLISH=0: the copy + synchronise of rounds 1-2
+                if(use_publish)
+                {
+                    if(int const prc = publish_and_wait(h, S.flags, &eta_now); prc != PE_HIP_OK) return prc;
+                }
+                else if(int const drc = download_flags(h, S.flags); drc != PE_HIP_OK)
+                    return drc;  // (synchronises the stream)
                 float kms = 0.f;
                 if(hipEventElapsedTime(&kms, h->evk0, h->evk1) == hipSuccess)
                 {

@@ -225,7 +225,9 @@ namespace pe_eng PE_ENG_HIDDEN
             V.quad = stride < (1ll << 31) ? (knob(h, "QUAD", 1) | 1) : 0;
             // the same fronts' backward pass on the lane-group kernel -- from 192 instances on: at 128 (one of its wavefronts per SIMD) the
             // per-instance backward pass of the parts is 1.3 % faster per iteration, at 256 they are equal (profiles/r03_ab_runs.log ab22)
-            V.quad_back = (V.quad && knob(h, "QUAD_BACK", geometry_batch(h, batch) >= 192 ? 1 : 0) != 0) ? 1 : 0;
+            // (round 4: with the ancestors' unknowns fetched by two loads + row broadcasts the lane-group backward kernel wins at 128 instances
+            //  too -- 1.378 against 1.403 ms per iteration, profiles/r04_ab_runs.log -- : on wherever the lane-group kernel is)
+            V.quad_back = (V.quad && knob(h, "QUAD_BACK", 1) != 0) ? 1 : 0;
         }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
@@ -515,6 +517,7 @@ namespace pe_eng PE_ENG_HIDDEN
                 std::fprintf(stderr, "\n");
             }
         }
+        pe::m2_graphs_clear(h->graphs);  // (captured sequences hold the old view: its tables are about to be freed)
         h->sym_pool.release();
         int const rc = upload_symbolic(h, h->sym_pool, h->sym, so, h->V, h->hc.batch);
         if(rc != PE_HIP_OK) return rc;
@@ -525,6 +528,32 @@ namespace pe_eng PE_ENG_HIDDEN
             std::fprintf(stderr, "[pe_hip]   top fronts, LDS layout (0 whole, 1 panels, 2 chain link, 3 chain link continued in LDS; * = 16-wavefront level, %d doubles):", h->V.lds_top_doubles);
             for(std::size_t l = 0; l + 1 < S.top_ptr.size(); ++l)
                 for(int k = S.top_ptr[l]; k < S.top_ptr[l + 1]; ++k) std::fprintf(stderr, " %d%s", S.f_mode[S.top_list[k]], h->V.top_wide[l] ? "*" : "");
+            std::fprintf(stderr, "\n");
+        }
+        if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')
+        {
+            // panel-layout Schur tiles by the number of children they pull (front_factor: the first two are requested a tile ahead, the rest one by one)
+            auto const& S = h->sym;
+            long long hist[8]{}, tiles = 0;
+            for(int s = 0; s < S.nfronts; ++s)
+            {
+                if(S.f_kind[s] == 0 || S.f_mode[s] != 1) continue;
+                int const u = S.f_u[s], nt = (u + 15) / 16, ch0 = S.f_child_ptr[s], ch1 = S.f_child_ptr[s + 1];
+                for(int tj = 0; tj < nt; ++tj)
+                    for(int ti = 0; ti < nt; ++ti)
+                    {
+                        int n = 0;
+                        for(int c = ch0; c < ch1; ++c)
+                        {
+                            unsigned const mk = S.f_bmask[static_cast<size_t>(c)];
+                            n += static_cast<int>(((mk >> std::min(ti, 31)) & (mk >> std::min(tj, 31))) & 1u);
+                        }
+                        ++hist[std::min(n, 7)];
+                        ++tiles;
+                    }
+            }
+            std::fprintf(stderr, "[pe_hip]   panel-layout Schur tiles by children pulled (0..7+) of %lld:", tiles);
+            for(long long v: hist) std::fprintf(stderr, " %lld", v);
             std::fprintf(stderr, "\n");
         }
         if(char const* dump = std::getenv("PHY_ENGINE_HIP_DUMP_SCHEDULE"); dump && *dump == '1')

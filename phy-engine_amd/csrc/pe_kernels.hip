@@ -16,8 +16,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "pe_front.hpp"
 #include "pe_kernels.hpp"
@@ -1092,7 +1094,9 @@ namespace pe
     static int grid_per_instance(DevView const& V)
     {
         if(V.ew_grid > 0) return V.ew_grid;  // knob EW_GRID of this engine (sweeps): workgroups per instance, as given
-        int const by_rows = (V.rows + 2047) / 2048, fine = (V.rows + 255) / 256, want = 512 / (V.batch > 0 ? V.batch : 1);
+        // (round 4: 1 280 workgroups in all -- ten per instance at 128 instances, 1.376 against 1.395 ms per iteration; 256 instances and more
+        //  are at rows / 2 048 either way)
+        int const by_rows = (V.rows + 2047) / 2048, fine = (V.rows + 255) / 256, want = 1280 / (V.batch > 0 ? V.batch : 1);
         int g = by_rows > (want < fine ? want : fine) ? by_rows : (want < fine ? want : fine);
         return g < 1 ? 1 : (g > 64 ? 64 : g);
     }
@@ -1246,6 +1250,143 @@ namespace pe
     {
         hipLaunchKernelGGL(k_m2_publish, dim3(1), dim3(256), 0, st, V.flags, V.residual_tol > 0.0 ? V.eta_acc : nullptr, V.batch, pub_flags, pub_eta, pub_seq, seq);
         return hipGetLastError();
+    }
+
+    // ---- captured launch sequences (hipGraph) of the split schedule.  One Newton iteration of a small sweep is 15-20 short launches; enqueued one
+    // by one the host call rate (3-5 us per launch) is of the order of the kernels themselves (3-15 us for the elementwise and top-solve launches
+    // of a single circuit) and the stream runs dry between them.  The sequence of an iteration is fixed by (analysis mode, factor / reuse, full /
+    // x-dependent stamp, companion update yes / no) and the view V: it is captured ONCE per such key into a graph and replayed with one
+    // hipGraphLaunch; what changes from iteration to iteration -- t, last_step, the companion's dt (arguments of k_m2_eval) and the sequence number
+    // of k_m2_publish -- is patched into those two nodes (hipGraphExecKernelNodeSetParams).  The instances that still iterate are device data
+    // (V.active, the quad list): the captured grids are those of the full sweep, finished instances return at once.
+    struct M2GraphEntry
+    {
+        hipGraph_t graph{};
+        hipGraphExec_t exec{};
+        hipGraphNode_t eval_node{}, publish_node{};
+        DevView V{};
+        int mode{}, do_factor{}, dyn{}, companion{};
+        int* pub_flags{};
+        double* pub_eta{};
+        unsigned long long* pub_seq{};
+    };
+    struct M2GraphCache
+    {
+        std::vector<M2GraphEntry> entries;
+        ~M2GraphCache() { clear(); }
+        void clear()
+        {
+            for(auto& e: entries)
+            {
+                if(e.exec) (void)hipGraphExecDestroy(e.exec);
+                if(e.graph) (void)hipGraphDestroy(e.graph);
+            }
+            entries.clear();
+        }
+    };
+    M2GraphCache* m2_graphs_create() { return new M2GraphCache; }
+    void m2_graphs_destroy(M2GraphCache* c) { delete c; }
+    void m2_graphs_clear(M2GraphCache* c)
+    {
+        if(c) c->clear();
+    }
+
+    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, bool stamp_dynamic,
+                                         bool companion, double companion_dt, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq)
+    {
+        int const dyn = (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0;
+        M2GraphEntry* hit = nullptr;
+        for(auto& e: cache->entries)
+            if(e.mode == mode && e.do_factor == (do_factor ? 1 : 0) && e.dyn == dyn && e.companion == (companion ? 1 : 0) && e.pub_flags == pub_flags && e.pub_eta == pub_eta &&
+               e.pub_seq == pub_seq && std::memcmp(&e.V, &V, sizeof(DevView)) == 0)
+            {
+                hit = &e;
+                break;
+            }
+        if(!hit)
+        {
+            if(cache->entries.size() >= 16) cache->clear();  // (a view that keeps changing: start over rather than grow)
+            M2GraphEntry e;
+            std::memcpy(&e.V, &V, sizeof(DevView));  // (bytes, padding included: the key is compared with memcmp)
+            e.mode = mode;
+            e.do_factor = do_factor ? 1 : 0;
+            e.dyn = dyn;
+            e.companion = companion ? 1 : 0;
+            e.pub_flags = pub_flags;
+            e.pub_eta = pub_eta;
+            e.pub_seq = pub_seq;
+            hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if(rc != hipSuccess) return rc;
+            rc = V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_dynamic, companion, companion_dt)
+                                  : m2_sequence<2>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_dynamic, companion, companion_dt);
+            hipError_t const rp = launch_m2_publish(st, V, pub_flags, pub_eta, pub_seq, seq);
+            hipError_t const re = hipStreamEndCapture(st, &e.graph);
+            if(rc != hipSuccess) return rc;
+            if(rp != hipSuccess) return rp;
+            if(re != hipSuccess) return re;
+            rc = hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0);
+            if(rc != hipSuccess)
+            {
+                (void)hipGraphDestroy(e.graph);
+                return rc;
+            }
+            size_t n = 0;
+            rc = hipGraphGetNodes(e.graph, nullptr, &n);
+            if(rc != hipSuccess) return rc;
+            std::vector<hipGraphNode_t> nodes(n);
+            rc = hipGraphGetNodes(e.graph, nodes.data(), &n);
+            if(rc != hipSuccess) return rc;
+            for(hipGraphNode_t nd: nodes)
+            {
+                hipGraphNodeType ty{};
+                if(hipGraphNodeGetType(nd, &ty) != hipSuccess || ty != hipGraphNodeTypeKernel) continue;
+                hipKernelNodeParams kp{};
+                if(hipGraphKernelNodeGetParams(nd, &kp) != hipSuccess) continue;
+                if(kp.func == reinterpret_cast<void*>(&k_m2_eval)) e.eval_node = nd;
+                else if(kp.func == reinterpret_cast<void*>(&k_m2_publish))
+                    e.publish_node = nd;
+            }
+            if(!e.eval_node || !e.publish_node)
+            {
+                (void)hipGraphExecDestroy(e.exec);
+                (void)hipGraphDestroy(e.graph);
+                return hipErrorInvalidValue;
+            }
+            cache->entries.push_back(e);
+            hit = &cache->entries.back();
+        }
+        // this iteration's scalars into the two nodes that take them
+        {
+            DevView v = V;
+            int md = mode, dy = dyn, cs = companion ? 1 : 0;
+            double tt = t, ls = last_step, cd = companion_dt;
+            void* args[] = {&v, &md, &tt, &ls, &dy, &cs, &cd};
+            hipKernelNodeParams kp{};
+            hipError_t rc = hipGraphKernelNodeGetParams(hit->eval_node, &kp);
+            if(rc != hipSuccess) return rc;
+            kp.kernelParams = args;
+            kp.extra = nullptr;
+            rc = hipGraphExecKernelNodeSetParams(hit->exec, hit->eval_node, &kp);
+            if(rc != hipSuccess) return rc;
+        }
+        {
+            int const* fl = V.flags;
+            double const* eta = V.residual_tol > 0.0 ? V.eta_acc : nullptr;
+            int batch = V.batch;
+            int* pf = pub_flags;
+            double* pe_ = pub_eta;
+            unsigned long long* ps = pub_seq;
+            unsigned long long sq = seq;
+            void* args[] = {&fl, &eta, &batch, &pf, &pe_, &ps, &sq};
+            hipKernelNodeParams kp{};
+            hipError_t rc = hipGraphKernelNodeGetParams(hit->publish_node, &kp);
+            if(rc != hipSuccess) return rc;
+            kp.kernelParams = args;
+            kp.extra = nullptr;
+            rc = hipGraphExecKernelNodeSetParams(hit->exec, hit->publish_node, &kp);
+            if(rc != hipSuccess) return rc;
+        }
+        return hipGraphLaunch(hit->exec, st);
     }
 
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt)

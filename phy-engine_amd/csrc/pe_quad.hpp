@@ -720,6 +720,7 @@ namespace pe
         using vm = typename X::vm;
         int const* ql = V.q_list + static_cast<long long>(quad) * 4;
         int const b0 = ql[0];
+        if(b0 < 0) return;  // an empty quad: a captured launch sequence keeps the grid of the full sweep, converged instances leave holes at the end
         vi const lane = X::lane();
         vi const q = lane >> 4;
         vi const b = X::ld_i32(ql, X::to_u(q) << 2);
@@ -784,6 +785,7 @@ namespace pe
         if(nfr <= 0) return;
         int const* ql = V.q_list + static_cast<long long>(quad) * 4;
         int const b0 = ql[0];
+        if(b0 < 0) return;  // an empty quad: a captured launch sequence keeps the grid of the full sweep, converged instances leave holes at the end
         vi const lane = X::lane();
         vi const q = lane >> 4;
         vi const b = X::ld_i32(ql, X::to_u(q) << 2);
@@ -849,6 +851,7 @@ namespace pe
         for(int L = 0; L < list; ++L) first += V.q_lists[2 * L + 1];
         int const* ql = V.q_list + static_cast<long long>(quad) * 4;
         int const b0 = ql[0];
+        if(b0 < 0) return;  // (an empty quad, see quad_factor_list)
         vi const lane = X::lane();
         vi const q = lane >> 4, r = lane & 15;
         vi const b = X::ld_i32(ql, X::to_u(q) << 2);

@@ -333,6 +333,21 @@ namespace pe
         return hipSuccess;
     }
 
+    // (captured launch sequences are a device matter: the emulation runs the plain sequence and the publication)
+    struct M2GraphCache
+    {
+        int launches{};
+    };
+    M2GraphCache* m2_graphs_create() { return new M2GraphCache; }
+    void m2_graphs_destroy(M2GraphCache* c) { delete c; }
+    void m2_graphs_clear(M2GraphCache*) {}
+    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, bool stamp_dynamic,
+                                         bool companion, double companion_dt, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq)
+    {
+        ++cache->launches;
+        hipError_t const rc = launch_m2_iteration(st, V, mode, t, last_step, do_factor, nullptr, nullptr, stamp_dynamic, companion, companion_dt);
+        return rc != hipSuccess ? rc : launch_m2_publish(st, V, pub_flags, pub_eta, pub_seq, seq);
+    }
     hipError_t launch_m2_refine(hipStream_t, DevView const& V)
     {
         std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
