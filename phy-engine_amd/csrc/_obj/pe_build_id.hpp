@@ -1,1 +1,1 @@
-#define PE_BUILD_ID "6afc8e02b2fce425"
+#define PE_BUILD_ID "ef6dec4640c1f2f4"

@@ -121,6 +121,8 @@ struct pe_hip_engine
     bool graph_mode{};            // the quad list behind the device's `active` mask is laid out for a captured sequence (full grid)
     double* stats_scratch{};      // pe_hip_sweep_statistics: partial sums + result (device, owned by circ_pool)
     size_t stats_doubles{};
+    double* stats_pinned{};       // pinned host landing buffer of its result (owned by the engine)
+    size_t stats_pinned_bytes{};
     Pool circ_pool;  // topology, params, state
     Pool sym_pool;   // symbolic arrays + factor storage
     pe::Symbolic sym;
