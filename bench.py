@@ -65,6 +65,33 @@ def reduce_statistics(local, dist=None, device=None):
     return torch.cat([sums, -ext[:1], ext[1:]]).cpu().numpy()
 
 
+def select_traffic(profiles_dir, build_id, B, nonlinear, W, kernel, algorithmic_bytes_per_launch):
+    """roofline.traffic from the committed PMC summaries (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.py): the newest one
+    measured for this configuration (instances per GPU, mesh, variant, kernel) counts -- and only when it was measured on THIS build of
+    the library (pe_hip_build_id: hash of its sources and flags).  A figure from another build is reported as stale, never carried over."""
+    out = {}
+    try:
+        names = sorted((f for f in os.listdir(profiles_dir) if f.endswith("_pmc_traffic.json")), reverse=True)
+    except OSError:
+        return out
+    for tp in names:
+        try:
+            tj = json.load(open(os.path.join(profiles_dir, tp)))
+        except Exception:
+            continue
+        if not (tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W and
+                tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]):
+            continue
+        if build_id and tj.get("build_id") == build_id:
+            return {"traffic": tj["hbm_bytes_per_launch"], "traffic_over_algorithmic": tj["hbm_bytes_per_launch"] / algorithmic_bytes_per_launch,
+                    "traffic_source": f"profiles/{tp} (build_id {tj['build_id']}): " + tj.get("note", "")}
+        if "traffic_stale" not in out:
+            out = {"traffic": None, "traffic_stale": True,
+                   "traffic_source": f"none for build_id {build_id}: the newest summary for this configuration, profiles/{tp}, is of build "
+                                     f"{tj.get('build_id', 'unknown (before round 4)')} ({tj['hbm_bytes_per_launch']:.4g} B per launch there)"}
+    return out
+
+
 def shard(total, world, rank):
     """Contiguous blocks of ceil(total / world) instances per rank (the last ranks may get fewer, or none)."""
     chunk = -(-total // world)
@@ -409,25 +436,7 @@ def main():
         # HBM bytes of the dominant kernel from the PMC counters: OFFLINE figure (rocprofv3 cannot profile the process that prints
         # this line) -- two separate --pmc passes of this same command, corrected with the factors calibrated on this engine's
         # access shapes (scripts/hbm_calib.hip); copied from the committed summary only when it was measured for this configuration
-        # ... and only when that summary was measured on THIS build of the library (pe_hip_build_id: hash of its sources and flags):
-        # a figure from another library is reported as stale, never silently carried over
-        for tp in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tp)))
-            except Exception:
-                continue
-            if not (tj.get("instances_per_gpu") == B and tj.get("nonlinear") == nonlinear and tj.get("mesh") == W and
-                    tj.get("kernel", "").split("<")[0] == kernel.split("<")[0]):
-                continue
-            if tj.get("build_id") == line["build_id"]:
-                line["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
-                line["roofline"]["traffic_over_algorithmic"] = tj["hbm_bytes_per_launch"] / (dom_bytes / dom_launches)
-                line["roofline"]["traffic_source"] = f"profiles/{tp} (build_id {tj['build_id']}): " + tj.get("note", "")
-                line["roofline"].pop("traffic_stale", None)
-                break
-            line["roofline"]["traffic_stale"] = True
-            line["roofline"].setdefault("traffic_source", f"none for build_id {line['build_id']}: newest summary profiles/{tp} is of build "
-                                                          f"{tj.get('build_id', 'unknown (before round 4)')} ({tj['hbm_bytes_per_launch']:.4g} B per launch there)")
+        line["roofline"].update(select_traffic(os.path.join(ROOT, "profiles"), line["build_id"], B, nonlinear, W, kernel, dom_bytes / dom_launches))
         if world == 1 and not args.no_single:
             # extra (outside the timed region): ONE M10k circuit on the GPU -- the latency-bound case of config C3
             try:

@@ -219,6 +219,18 @@ int finish_load(pe_hip_engine* h)
     apply_options(h, V);
     h->V = V;
     h->loaded = true;
+    // One dry run of the sweep's exchange step (statistics kernels + the asynchronous copy of their result into the pinned buffer) on the
+    // zeroed solution: the first use of that path costs the runtime 7-8 ms (first asynchronous device-to-host copy of the stream: copy-queue
+    // set-up; measured with scripts/r4_reduce_probe.py: 7.4 ms, then 0.07 ms) -- paid here, with the load, instead of on every rank's
+    // critical path in front of the all-reduce.
+    if(hc.rows > 0 && h->stats_pinned)
+    {
+        int const n_chunks = stats_chunks(hc.batch);
+        double* dev_out = h->stats_scratch + static_cast<size_t>(n_chunks) * 4 * hc.rows;
+        HIPCHK(h, pe::launch_sweep_statistics(h->stream, h->V, n_chunks, h->stats_scratch, dev_out));
+        HIPCHK(h, hipMemcpyAsync(h->stats_pinned, dev_out, static_cast<size_t>(4) * hc.rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
     return PE_HIP_OK;
 }
 }  // namespace pe_eng

@@ -3,6 +3,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from parity_common import ROOT
 
 WORKER = r'''
@@ -42,3 +44,23 @@ def test_sweep_reduction_world2(tmp_path):
                           "--master-port", "29631", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_copies_pmc_traffic_only_from_the_same_library_build(tmp_path):
+    """roofline.traffic is an OFFLINE figure (rocprofv3 --pmc passes, scripts/pmc_traffic.py).  Round 3 copied it whenever batch / mesh /
+    kernel matched; now it also has to carry the build id of the library that prints the line (pe_hip_build_id), else the line says
+    traffic null + traffic_stale and names the build the newest summary belongs to."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    base = {"instances_per_gpu": 1024, "nonlinear": True, "mesh": 100, "kernel": "k_m2_factor_quads + k_m2_factor_parts", "hbm_bytes_per_launch": 13.0e9, "note": "n"}
+    (tmp_path / "r03_pmc_traffic.json").write_text(json.dumps(base))                                   # round 3: no build id at all
+    (tmp_path / "r04_pmc_traffic.json").write_text(json.dumps(dict(base, build_id="aaaa", hbm_bytes_per_launch=12.0e9)))
+    (tmp_path / "r04x_pmc_traffic.json").write_text(json.dumps(dict(base, build_id="bbbb", instances_per_gpu=128)))   # another configuration
+    args = (1024, True, 100, "k_m2_factor_quads + k_m2_factor_parts<4>", 10.0e9)
+    hit = bench.select_traffic(str(tmp_path), "aaaa", *args)
+    assert hit["traffic"] == 12.0e9 and hit["traffic_over_algorithmic"] == pytest.approx(1.2) and "aaaa" in hit["traffic_source"] and "traffic_stale" not in hit
+    stale = bench.select_traffic(str(tmp_path), "cccc", *args)
+    assert stale["traffic"] is None and stale["traffic_stale"] is True and "aaaa" in stale["traffic_source"] and "cccc" in stale["traffic_source"]
+    assert bench.select_traffic(str(tmp_path), "aaaa", 256, True, 100, args[3], 1.0) == {}                # nothing measured for that configuration
+    assert bench.select_traffic(str(tmp_path / "missing"), "aaaa", *args) == {}

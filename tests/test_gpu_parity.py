@@ -853,3 +853,42 @@ e.close()
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][0], out[1][0])   # bit for bit
     assert out[0][1].min() > 12                   # (several Newton iterations per step: the x-dependent-only path did run)
+
+
+@pytest.mark.gpu
+def test_round4_launch_variants_are_bit_identical(tmp_path):
+    """Round 4 changed HOW an iteration of the split schedule is launched, not what it computes: (a) one captured launch sequence (hipGraph)
+    per Newton iteration for small sweeps (knob GRAPH), grids of the full sweep with finished instances leaving empty quads; (b) the step's
+    companion update inside the first evaluation launch (knob COMPANION_LAUNCH=1: a launch of its own, as before) and w = P rhs written by
+    the stamp launch; (c) the backward lane-group kernel on at every sweep size (knob QUAD_BACK) with the ancestors' unknowns fetched by row
+    broadcasts.  A 6-instance sweep of the 10k-node diode mesh (instances converge at different iterations: the active set shrinks inside a
+    time point) under the geometry of the 128-instance share: every variant ends on the same bits and the same Newton counts."""
+    import subprocess
+    import sys
+    from parity_common import ROOT
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load()
+deck, r, c = pe.deck.rc_mesh_params(100, 100, [3, 4, 5, 6, 7, 8], True)
+e = pe.ffi.Engine(device=0); e.set_options(g_min=0.0)
+e.load_deck(deck, batch=6, overrides={{"R": r[:, :, None], "C": c[:, :, None]}})
+e.reset(); st = e.analyze_tr(1e-10, 12)
+assert e.info()["n_parts"] > 1 and e.info()["n_quad_fronts"] > 0
+np.save(sys.argv[1], e.solution()); np.save(sys.argv[1] + ".it", e.state()["iters"])
+e.close()
+"""
+    out = {}
+    variants = {"default": {}, "graph": {"PHY_ENGINE_HIP_GRAPH": "1"}, "no_graph": {"PHY_ENGINE_HIP_GRAPH": "0"},
+                "own_companion_launch": {"PHY_ENGINE_HIP_GRAPH": "0", "PHY_ENGINE_HIP_COMPANION_LAUNCH": "1"},
+                "per_instance_backward": {"PHY_ENGINE_HIP_QUAD_BACK": "0"}}
+    for name, knobs in variants.items():
+        f = str(tmp_path / f"{name}.npy")
+        env = dict(os.environ, PHY_ENGINE_HIP_GEOMETRY_BATCH="128", **knobs)
+        subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=600)
+        out[name] = (np.load(f), np.load(f + ".it.npy"))
+    for name in variants:
+        assert np.array_equal(out[name][1], out["default"][1]), name
+        assert np.array_equal(out[name][0], out["default"][0]), name   # bit for bit
+    assert len(set(out["default"][1].tolist())) > 1 or out["default"][1].min() > 12   # (the instances do not move in lockstep)
