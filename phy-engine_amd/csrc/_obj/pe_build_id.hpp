@@ -1,1 +1,1 @@
-#define PE_BUILD_ID "327c356ce398d647"
+#define PE_BUILD_ID "0d989e1dedfa23bf"

@@ -324,6 +324,7 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
                                       hipMemcpyHostToDevice));
             }
         h->fact_valid = false;
+        h->a_static.clear();
     }
     if(h->loaded && gmin_changed)
     {
@@ -332,6 +333,7 @@ int pe_hip_set_options(pe_hip_engine* h, const pe_hip_options* o)
         HIPCHK(h, hipMemcpy2D(h->V.dv + pe::DV_GMIN, h->hc.dv_len * sizeof(double), col.data(), sizeof(double), sizeof(double), h->hc.batch,
                               hipMemcpyHostToDevice));
         h->fact_valid = false;
+        h->a_static.clear();
     }
     return PE_HIP_OK;
 }
@@ -415,6 +417,7 @@ int pe_hip_load_circuit(pe_hip_engine* h, int n_nodes, int n_branches, int batch
     h->loaded = false;
     h->sym_class = -1;
     h->fact_valid = false;
+    h->a_static.clear();
     pe::m2_graphs_clear(h->graphs);  // (captured launch sequences point into the circuit being replaced)
     h->circ_pool.release();
     h->stats_scratch = nullptr;
@@ -518,6 +521,7 @@ int pe_hip_reset(pe_hip_engine* h)
     HIPCHK(h, hipMemset(V.trace_len, 0, sizeof(int)));
     HIPCHK(h, hipMemset(V.prof, 0, B * pe::PE_PROF * sizeof(long long)));
     h->fact_valid = false;
+    h->a_static.clear();
     return PE_HIP_OK;
 }
 
@@ -667,6 +671,7 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
         if(kind == PE_HIP_VGEN && column == 0) return fail(h, PE_HIP_ERR_ARG, "update_param: the generator type is fixed at load time");
         std::vector<double> col(B);
         h->fact_valid = false;
+        h->a_static.clear();
         for(int b = 0; b < B; ++b)
         {
             hc.gen_par[static_cast<size_t>(b) * hc.gen_par_len + d.par + column] = val(b);
@@ -708,6 +713,7 @@ int pe_hip_update_param(pe_hip_engine* h, int kind, int index, int column, const
     if(j < 0) return PE_HIP_OK;  // device with an unconnected pin: nothing resident
     std::vector<double> col(B);
     h->fact_valid = false;
+    h->a_static.clear();
     switch(kind)
     {
         case PE_HIP_R:

@@ -130,6 +130,7 @@ int pe_hip_checkpoint_load(pe_hip_engine* h, const void* buffer, size_t size)
         if(!dv.empty()) HIPCHK(h, hipMemcpy(h->V.dv, dv.data(), dv.size() * sizeof(double), hipMemcpyHostToDevice));
     }
     h->fact_valid = false;
+    h->a_static.clear();
     return PE_HIP_OK;
 }
 

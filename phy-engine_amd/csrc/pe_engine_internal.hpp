@@ -131,6 +131,10 @@ struct pe_hip_engine
     pe::DevView V{};
     bool fact_valid{};
     double fact_dt{};
+    // split schedule: instances whose matrix (aval) holds a FULL transient stamp at step size a_static_dt -- their next steps at that dt stamp
+    // the x-dependent slots only (pe_engine_newton.cpp run_m2_tr); cleared together with fact_valid wherever a static value may change
+    std::vector<char> a_static;
+    double a_static_dt{-1.0};
     double analyze_ms{};
 
     // small-signal AC: a second engine holding the real-equivalent 2N system (pe_ac.hpp), built on first use

@@ -293,8 +293,10 @@ namespace pe_eng PE_ENG_HIDDEN
 
     // one solve point of every instance whose status is OK; result[b] = iterations (> 0) or a negative status
     // companion_dt != null: a transient step -- its companion update rides in the first iteration's evaluation launch (k_m2_eval)
+    // a_static_ok: the non-x-dependent part of every active instance's matrix already holds the stamp of this (mode, dt) -- the first iteration
+    // stamps the x-dependent slots + the whole right-hand side only (stamp mode 2)
     int m2_point(pe_hip_engine* h, M2State& S, int mode, double t, double last_step, bool do_factor, std::vector<int>& result, int& launches,
-                 double const* companion_dt = nullptr)
+                 double const* companion_dt = nullptr, bool a_static_ok = false)
     {
         int const B = h->hc.batch;
         result.assign(B, 0);
@@ -325,7 +327,8 @@ namespace pe_eng PE_ENG_HIDDEN
             if(int const urc = upload_active(h, S.active); urc != PE_HIP_OK) return urc;
             // (test knob PHY_ENGINE_HIP_FULL_STAMP=1: every iteration stamps everything -- the x-dependent-only path must match it bit for bit)
             static bool const full_stamp = env_int0("PHY_ENGINE_HIP_FULL_STAMP", 0) != 0;
-            bool const dyn = it > 0 && !full_stamp, comp = it == 0 && companion_dt != nullptr;
+            int const dyn = full_stamp ? 0 : (it > 0 ? 1 : (a_static_ok ? 2 : 0));
+            bool const comp = it == 0 && companion_dt != nullptr;
             std::vector<double> eta_now;
             if(graph_mode)
             {
@@ -339,7 +342,7 @@ namespace pe_eng PE_ENG_HIDDEN
             }
             else
             {
-                HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_dynamic=*/dyn, /*companion=*/comp,
+                HIPCHK(h, pe::launch_m2_iteration(h->stream, h->V, mode, t, last_step, do_factor, h->evk0, h->evk1, /*stamp_mode=*/dyn, /*companion=*/comp,
                                                   companion_dt ? *companion_dt : 0.0));
                 ++launches;
                 // flags + residual norms of this iteration: published into pinned host memory by the iteration's last launch and polled
@@ -454,7 +457,25 @@ namespace pe_eng PE_ENG_HIDDEN
             double const t = t_prev + dt;
             // linear circuit, same dt as the last factorisation: stamp + triangular solves only
             bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
-            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, !reuse, res, launches, (with_companion && !own_launch) ? &dt : nullptr);
+            // The matrix of a transient step differs from the last step's only in its x-dependent slots while dt and the parameters stay (the
+            // companion conductances 2C/dt, 2L/dt are constants of the step size): instances whose matrix holds a full stamp of this dt skip the
+            // other 97 % of the matrix gather on the first iteration too (k_m2_stamp 0.56 -> 0.2 ms per time point at 1 024 instances).  The
+            // set is cleared wherever a static value can change (a_static_invalidate: parameters, options, load, checkpoint, re-analysis,
+            // any OP / DC / TROP solve -- they stamp other companions); knob STATIC_A=0: always the full stamp.
+            static bool const static_a = env_int0("PHY_ENGINE_HIP_STATIC_A", 1) != 0;
+            bool a_static_ok = static_a && h->a_static_dt == dt && h->a_static.size() == static_cast<size_t>(B);
+            for(int b = 0; b < B && a_static_ok; ++b)
+                if(S.active[b] && !h->a_static[static_cast<size_t>(b)]) a_static_ok = false;
+            rc = m2_point(h, S, PE_HIP_MODE_TR, t, dt, !reuse, res, launches, (with_companion && !own_launch) ? &dt : nullptr, a_static_ok);
+            if(rc == PE_HIP_OK && !a_static_ok)
+            {
+                // the first iteration of this step stamped everything for the instances that were active at its start (S.active is spent by now:
+                // the mask of the step is status OK && (!only || only[b]) -- recomputed)
+                if(h->a_static_dt != dt || h->a_static.size() != static_cast<size_t>(B)) h->a_static.assign(static_cast<size_t>(B), 0);
+                h->a_static_dt = dt;
+                for(int b = 0; b < B; ++b)
+                    if(res[b] != 0) h->a_static[static_cast<size_t>(b)] = 1;  // (res != 0: the instance took part in this point)
+            }
             if(rc != PE_HIP_OK) return rc;
             if(may_reuse)
             {
@@ -491,6 +512,7 @@ namespace pe_eng PE_ENG_HIDDEN
         std::vector<double> ls(B);
         HIPCHK(h, hipMemcpy(ls.data(), h->V.last_step, B * sizeof(double), hipMemcpyDeviceToHost));
         std::vector<int> res;
+        h->a_static.clear();  // (an OP / DC / TROP stamp overwrites the transient companions in the matrix)
         rc = m2_point(h, S, mode, S.t[0], ls[0], true, res, launches);
         if(rc != PE_HIP_OK) return rc;
         for(int b = 0; b < B; ++b)
@@ -597,6 +619,7 @@ int pe_hip_analyze_tr(pe_hip_engine* h, double dt, int nsteps, pe_hip_run_stats*
         if(rc != PE_HIP_OK) return rc;
         done = nsteps;
     }
+    if(done < nsteps) h->a_static.clear();  // (the resident kernel stamps the matrix itself: what the split schedule knew about it is void)
     while(done < nsteps)
     {
         bool const reuse = may_reuse && h->fact_valid && h->fact_dt == dt;
@@ -656,6 +679,7 @@ int pe_hip_analyze_dc(pe_hip_engine* h, int mode, pe_hip_run_stats* st)
     rc = snapshot_counters(h, s0, i0);
     if(rc != PE_HIP_OK) return rc;
     h->fact_valid = false;
+    h->a_static.clear();  // (an OP / DC / TROP solve stamps other companion values into the matrix, on either schedule)
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if(split_launch(h))
     {

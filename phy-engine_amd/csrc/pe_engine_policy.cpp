@@ -615,6 +615,7 @@ namespace pe_eng PE_ENG_HIDDEN
         }
         h->sym_class = cls;
         h->fact_valid = false;
+        h->a_static.clear();
         h->analyze_ms = ms_since(t0);
         return PE_HIP_OK;
     }

@@ -471,7 +471,10 @@ namespace pe
     // (same lists, same summation order: bit-identical to a full stamp); everything else still holds the first iteration's values.
     // with_w (split schedule): w = P rhs as well -- every gathered row writes its own entry of w, the rows the dynamic stamp does not
     // gather are copied from the rhs of the first iteration (no thread reads what another one writes: no barrier, one launch less)
-    PE_DEV void stamp_dynamic_chunk(DevView const& V, int b, int g, int G, int t0, int T, bool with_w = false)
+    // rhs_full (first Newton iteration of a transient step whose matrix is known to hold the stamp of this dt, round 4): the matrix takes the
+    // x-dependent slots only -- everything else in A (conductances, companion conductances 2C/dt, 2L/dt, incidence, g_min) is the same from one
+    // time point to the next while dt and the parameters stay -- and the right-hand side (histories, sources at the new t) is gathered in full
+    PE_DEV void stamp_dynamic_chunk(DevView const& V, int b, int g, int G, int t0, int T, bool with_w = false, bool rhs_full = false)
     {
         double const* dv = V.dv + static_cast<long long>(b) * V.dv_len;
         double* w = with_w ? V.w + static_cast<long long>(b) * V.rows : nullptr;
@@ -484,6 +487,12 @@ namespace pe
         int lo, hi;
         range(V.n_dyn_a, lo, hi);
         gather_contributions<PE_STAMP_UN>(t0, T, V.a_ptr, V.a_src, dv, V.aval + static_cast<long long>(b) * V.nnzA, lo, hi, V.dyn_a);
+        if(rhs_full)
+        {
+            range(V.rows, lo, hi);
+            gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, nullptr, w, V.row_dst);
+            return;
+        }
         range(V.n_dyn_b, lo, hi);
         gather_contributions<PE_STAMP_UN>(t0, T, V.b_ptr, V.b_src, dv, V.rhs + static_cast<long long>(b) * V.rows, lo, hi, V.dyn_b, w, V.row_dst);
         if(with_w)

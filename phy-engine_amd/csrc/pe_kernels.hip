@@ -650,7 +650,8 @@ namespace pe
     {
         int const b = static_cast<int>(blockIdx.y);
         if(!V.active[b]) return;
-        if(dynamic_only) stamp_dynamic_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), true);
+        // dynamic_only: 0 everything, 1 the x-dependent slots and rows, 2 the x-dependent slots of the matrix + the whole right-hand side
+        if(dynamic_only) stamp_dynamic_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), true, dynamic_only == 2);
         else
             stamp_chunk(V, b, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), static_cast<int>(threadIdx.x), static_cast<int>(blockDim.x), true);
     }
@@ -1104,9 +1105,13 @@ namespace pe
     // ev0 / ev1 (may be null): HIP events recorded around the dominant launch (k_m2_factor_parts, or the backward
     // k_m2_solve_parts when the factors are reused) for the per-kernel roofline of bench.py.
     template <int MINW>
+    // stamp_mode: 0 full stamp, 1 x-dependent slots / rows only (later Newton iterations of a point), 2 x-dependent matrix slots + full right-hand
+    // side (first iteration of a transient step at an unchanged dt: the rest of the matrix is last step's)
     static hipError_t m2_sequence(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1, bool refine,
-                                  bool stamp_dynamic = false, bool companion = false, double companion_dt = 0.0)
+                                  int stamp_mode = 0, bool companion = false, double companion_dt = 0.0)
     {
+        bool const have_lists = V.dyn_a && V.dyn_b;
+        int const eval_dyn = (stamp_mode == 1 && have_lists) ? 1 : 0, stamp_dyn = have_lists ? stamp_mode : 0;
         size_t const lds = static_cast<size_t>(V.lds_doubles) * sizeof(double);
         size_t const lds_s = static_cast<size_t>(V.lds_solve_doubles) * sizeof(double);
         size_t const lds_st = static_cast<size_t>(V.lds_solve_top_doubles) * sizeof(double);  // (top fronts may carry more pivots: larger staged block)
@@ -1134,8 +1139,8 @@ namespace pe
         };
         if(!refine)
         {
-            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0, companion ? 1 : 0, companion_dt);
-            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0);  // (+ w = P rhs)
+            hipLaunchKernelGGL(k_m2_eval, dim3(G, B), dim3(256), 0, st, V, mode, t, last_step, eval_dyn, companion ? 1 : 0, companion_dt);
+            hipLaunchKernelGGL(k_m2_stamp, dim3(G, B), dim3(256), 0, st, V, stamp_dyn);  // (+ w = P rhs)
         }
         else  // (refinement: V arrives with rhs = the residual of the solve being corrected; the matrix values are still assembled)
             hipLaunchKernelGGL(k_m2_winit, dim3(G, B), dim3(256), 0, st, V);
@@ -1208,10 +1213,10 @@ namespace pe
     }
 
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0, hipEvent_t ev1,
-                                   bool stamp_dynamic, bool companion, double companion_dt)
+                                   int stamp_mode, bool companion, double companion_dt)
     {
-        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic, companion, companion_dt)
-                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_dynamic, companion, companion_dt);
+        return V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_mode, companion, companion_dt)
+                                : m2_sequence<2>(st, V, mode, t, last_step, do_factor, ev0, ev1, false, stamp_mode, companion, companion_dt);
     }
 
     // One round of iterative refinement of the active instances' last solve (same matrix values, same pivot order):
@@ -1291,10 +1296,10 @@ namespace pe
         if(c) c->clear();
     }
 
-    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, bool stamp_dynamic,
+    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, int stamp_mode,
                                          bool companion, double companion_dt, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq)
     {
-        int const dyn = (stamp_dynamic && V.dyn_a && V.dyn_b) ? 1 : 0;
+        int const dyn = (V.dyn_a && V.dyn_b) ? stamp_mode : 0;
         M2GraphEntry* hit = nullptr;
         for(auto& e: cache->entries)
             if(e.mode == mode && e.do_factor == (do_factor ? 1 : 0) && e.dyn == dyn && e.companion == (companion ? 1 : 0) && e.pub_flags == pub_flags && e.pub_eta == pub_eta &&
@@ -1317,8 +1322,8 @@ namespace pe
             e.pub_seq = pub_seq;
             hipError_t rc = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
             if(rc != hipSuccess) return rc;
-            rc = V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_dynamic, companion, companion_dt)
-                                  : m2_sequence<2>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_dynamic, companion, companion_dt);
+            rc = V.high_occupancy ? m2_sequence<4>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_mode, companion, companion_dt)
+                                  : m2_sequence<2>(st, V, mode, t, last_step, do_factor, nullptr, nullptr, false, stamp_mode, companion, companion_dt);
             hipError_t const rp = launch_m2_publish(st, V, pub_flags, pub_eta, pub_seq, seq);
             hipError_t const re = hipStreamEndCapture(st, &e.graph);
             if(rc != hipSuccess) return rc;
@@ -1358,7 +1363,7 @@ namespace pe
         // this iteration's scalars into the two nodes that take them
         {
             DevView v = V;
-            int md = mode, dy = dyn, cs = companion ? 1 : 0;
+            int md = mode, dy = dyn == 1 ? 1 : 0, cs = companion ? 1 : 0;  // (k_m2_eval: only mode 1 skips the x-independent values)
             double tt = t, ls = last_step, cd = companion_dt;
             void* args[] = {&v, &md, &tt, &ls, &dy, &cs, &cd};
             hipKernelNodeParams kp{};

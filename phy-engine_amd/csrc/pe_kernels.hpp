@@ -17,10 +17,11 @@ namespace pe
     hipError_t launch_factor_solve(hipStream_t st, DevView const& V, bool do_factor);
     // multi-workgroup mode (V.n_parts > 1)
     hipError_t launch_m2_companion(hipStream_t st, DevView const& V, double dt);
-    // stamp_dynamic: not the first Newton iteration of this solve point -- only the x-dependent slots are stamped again (V.dyn_a / dyn_b)
+    // stamp_mode: 0 everything; 1 not the first Newton iteration of this solve point -- only the x-dependent slots / rows are stamped again (V.dyn_a /
+    // dyn_b); 2 first iteration of a transient step whose matrix holds the stamp of this dt: x-dependent matrix slots + the whole right-hand side
     // companion: first iteration of a transient step -- the companion update of that step (dt = companion_dt) runs inside the evaluation launch
     hipError_t launch_m2_iteration(hipStream_t st, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t ev0 = nullptr,
-                                   hipEvent_t ev1 = nullptr, bool stamp_dynamic = false, bool companion = false, double companion_dt = 0.0);
+                                   hipEvent_t ev1 = nullptr, int stamp_mode = 0, bool companion = false, double companion_dt = 0.0);
     // the same sequence + the publication of its results (launch_m2_publish) as ONE captured graph launch, built on first use per (mode,
     // do_factor, stamp_dynamic, companion, V) and replayed afterwards; small sweeps only (pe_engine_newton.cpp).  No HIP events around the
     // dominant launch in this path.  The cache belongs to an engine (created / destroyed with it, cleared when its view changes for good).
@@ -28,7 +29,7 @@ namespace pe
     M2GraphCache* m2_graphs_create();
     void m2_graphs_destroy(M2GraphCache* c);
     void m2_graphs_clear(M2GraphCache* c);
-    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, bool stamp_dynamic,
+    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, int stamp_mode,
                                          bool companion, double companion_dt, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq);
     // device-to-device stream copy of `bytes` (multiple of 16): the kernel behind pe_hip_measure_hbm_ceiling
     hipError_t launch_stream_copy(hipStream_t st, void const* src, void* dst, size_t bytes);

@@ -246,9 +246,12 @@ namespace pe
             if(V.active[b]) companion_update(SerialTeam{1}, V, b, dt);
         return hipSuccess;
     }
-    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, bool stamp_dynamic,
+    hipError_t launch_m2_iteration(hipStream_t, DevView const& V, int mode, double t, double last_step, bool do_factor, hipEvent_t, hipEvent_t, int stamp_mode,
                                    bool companion, double companion_dt)
     {
+        bool const have_lists = V.dyn_a && V.dyn_b;
+        bool const stamp_dynamic = stamp_mode == 1;
+        int const stamp_dyn = have_lists ? stamp_mode : 0;
         std::vector<double> mem(static_cast<size_t>(std::max(V.lds_doubles, V.lds_top_doubles)) + 1);
         SerialTeam tm{V.n_waves};
         for(int b = 0; b < V.batch; ++b)
@@ -269,7 +272,7 @@ namespace pe
             for(int k = 0; k < V.rows; ++k) w[k] = std::nan("");
             for(int g = 0; g < 3; ++g)
             {
-                if(stamp_dynamic && V.dyn_a && V.dyn_b) stamp_dynamic_chunk(V, b, g, 3, 0, 1, true);
+                if(stamp_dyn) stamp_dynamic_chunk(V, b, g, 3, 0, 1, true, stamp_dyn == 2);
                 else
                     stamp_chunk(V, b, g, 3, 0, 1, true);
             }
@@ -341,11 +344,11 @@ namespace pe
     M2GraphCache* m2_graphs_create() { return new M2GraphCache; }
     void m2_graphs_destroy(M2GraphCache* c) { delete c; }
     void m2_graphs_clear(M2GraphCache*) {}
-    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, bool stamp_dynamic,
+    hipError_t launch_m2_iteration_graph(hipStream_t st, M2GraphCache* cache, DevView const& V, int mode, double t, double last_step, bool do_factor, int stamp_mode,
                                          bool companion, double companion_dt, int* pub_flags, double* pub_eta, unsigned long long* pub_seq, unsigned long long seq)
     {
         ++cache->launches;
-        hipError_t const rc = launch_m2_iteration(st, V, mode, t, last_step, do_factor, nullptr, nullptr, stamp_dynamic, companion, companion_dt);
+        hipError_t const rc = launch_m2_iteration(st, V, mode, t, last_step, do_factor, nullptr, nullptr, stamp_mode, companion, companion_dt);
         return rc != hipSuccess ? rc : launch_m2_publish(st, V, pub_flags, pub_eta, pub_seq, seq);
     }
     hipError_t launch_m2_refine(hipStream_t, DevView const& V)

@@ -861,7 +861,8 @@ def test_round4_launch_variants_are_bit_identical(tmp_path):
     per Newton iteration for small sweeps (knob GRAPH), grids of the full sweep with finished instances leaving empty quads; (b) the step's
     companion update inside the first evaluation launch (knob COMPANION_LAUNCH=1: a launch of its own, as before) and w = P rhs written by
     the stamp launch; (c) the backward lane-group kernel on at every sweep size (knob QUAD_BACK) with the ancestors' unknowns fetched by row
-    broadcasts.  A 6-instance sweep of the 10k-node diode mesh (instances converge at different iterations: the active set shrinks inside a
+    broadcasts; (d) the first iteration of a transient step at an unchanged dt stamps the x-dependent matrix slots + the right-hand side only
+    (knob STATIC_A=0: everything).  A 6-instance sweep of the 10k-node diode mesh (instances converge at different iterations: the active set shrinks inside a
     time point) under the geometry of the 128-instance share: every variant ends on the same bits and the same Newton counts."""
     import subprocess
     import sys
@@ -882,7 +883,7 @@ e.close()
     out = {}
     variants = {"default": {}, "graph": {"PHY_ENGINE_HIP_GRAPH": "1"}, "no_graph": {"PHY_ENGINE_HIP_GRAPH": "0"},
                 "own_companion_launch": {"PHY_ENGINE_HIP_GRAPH": "0", "PHY_ENGINE_HIP_COMPANION_LAUNCH": "1"},
-                "per_instance_backward": {"PHY_ENGINE_HIP_QUAD_BACK": "0"}}
+                "per_instance_backward": {"PHY_ENGINE_HIP_QUAD_BACK": "0"}, "always_full_stamp_at_a_new_time_point": {"PHY_ENGINE_HIP_STATIC_A": "0"}}
     for name, knobs in variants.items():
         f = str(tmp_path / f"{name}.npy")
         env = dict(os.environ, PHY_ENGINE_HIP_GEOMETRY_BATCH="128", **knobs)

@@ -448,6 +448,39 @@ except pe.ffi.PeHipError as e:
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
 
 
+def test_static_matrix_stamp_is_invalidated_by_everything_that_changes_it(emu_lib, tmp_path):
+    """Round 4: after a full stamp at step size dt the first Newton iteration of the following transient steps gathers only the x-dependent
+    matrix slots + the whole right-hand side (stamp mode 2; the rest of the matrix is the same from one time point to the next while dt and the
+    parameters stay).  The knowledge must be dropped by everything that changes a static value: a parameter update, another dt, an operating
+    point in between (it stamps the DC companions), g_min, a reset.  A scripted sequence of those, split schedule, two instances, against the
+    same sequence with the knob STATIC_A=0 (always the full stamp): bit for bit, same Newton counts."""
+    code = f"""
+import os, sys
+os.environ['PE_HIP_LIB'] = {emu_lib!r}
+sys.path.insert(0, {ROOT!r})
+import numpy as np, pe_load
+pe = pe_load.load()
+deck, r, c = pe.deck.rc_mesh_params(12, 12, [1, 2], True)
+e = pe.ffi.Engine(); e.set_knob('SPLIT', 1); e.set_knob('PARTS', 3); e.set_options(g_min=0.0)
+e.load_deck(deck, batch=2, overrides={{"R": r[:, :, None], "C": c[:, :, None]}}); e.reset()
+out = []
+def snap(): out.append(e.solution().copy()); out.append(np.array(e.state()['iters'], dtype=float))
+e.analyze_tr(1e-10, 4); snap()
+e.update_param(pe.ffi.R, 5, 0, [2500.0, 700.0]); e.analyze_tr(1e-10, 3); snap()      # a resistor changes: static slot
+e.analyze_tr(2e-10, 3); snap()                                                          # another step size: every companion conductance
+e.analyze_dc(pe.ffi.MODE_OP); snap(); e.analyze_tr(2e-10, 3); snap()                    # an operating point in between
+e.set_options(g_min=1e-9); e.analyze_tr(2e-10, 2); snap()                               # g_min sits on every node diagonal
+e.reset(); e.analyze_tr(2e-10, 3); snap()
+np.save(sys.argv[1], np.concatenate([o.ravel() for o in out]))
+"""
+    res = []
+    for knob in ("1", "0"):
+        f = str(tmp_path / f"s{{knob}}.npy".format(knob=knob))
+        subprocess.run(["python3", "-c", code, f], check=True, timeout=600, env=dict(os.environ, PHY_ENGINE_HIP_STATIC_A=knob))
+        res.append(np.load(f))
+    assert res[0].shape == res[1].shape and np.array_equal(res[0], res[1])
+
+
 def test_failed_solve_is_not_sticky_under_host_emulation(emu_lib):
     """circuit.h:242-254: a failed transient rolls tr_duration back and returns false; the NEXT analyze() tries again from that
     state.  Here: the g_min = 0 bridge fails (singular with all four diodes off), the caller raises g_min, and the same resident
