@@ -178,12 +178,14 @@ def single_circuit_numbers(pe, W, dt, device):
     """One M10k instance (no batch): NL and linear, full refactorisation per solve like the reference; and the linear
     circuit with the factors reused while dt is unchanged (legitimate for a linear circuit, SURVEY.md 8d -- flagged)."""
     out = {}
-    for key, nonlinear, refac, steps in (("nl_steps_per_s", True, 1, 60), ("linear_steps_per_s", False, 1, 60), ("linear_reuse_factor_steps_per_s", False, 0, 200)):
+    for key, nonlinear, refac, steps in (("nl_steps_per_s", True, 1, 30), ("linear_steps_per_s", False, 1, 60), ("linear_reuse_factor_steps_per_s", False, 0, 200)):
         eng = pe.ffi.Engine(device=device)
         eng.set_options(g_min=0.0, refactor_every_solve=refac)
         eng.load_deck(pe.deck.rc_mesh(W, W, 1, nonlinear))
         eng.reset()
-        eng.analyze_tr(dt, 10)
+        eng.analyze_tr(dt, 10)   # (throw-away run: GPU clocks, see shard_rates), then the window of rounds 1-3: 3 warm-up steps + `steps`
+        eng.reset()
+        eng.analyze_tr(dt, 3)
         st = eng.analyze_tr(dt, steps)
         out[key] = st["steps"] / (st["gpu_ms"] * 1e-3)
         if nonlinear:
@@ -207,13 +209,18 @@ def shard_rates(pe, W, dt, nonlinear, device, total=1024):
             eng.set_options(g_min=0.0)
             eng.load_deck(deck, batch=B, overrides={"R": r[:, :, None], "C": c[:, :, None]})
             eng.reset()
-            # (ten warm-up steps: these runs are 70-400 ms long and start right after a second of host-only work -- the symbolic analysis --
-            #  during which the GPU clocks fall back; with two warm-up steps the 128-instance figure moved by 7 % between runs of one library)
+            # (a throw-away run first: these measurements are 70-400 ms long and start right after a second of host-only work -- the symbolic
+            #  analysis -- during which the GPU clocks fall back; without it the 128-instance figure moved by 7 % between runs of one library.
+            #  Then the SAME window of the transient as the headline measurement: 2 warm-up steps + steps 3..22 -- the Newton iterations per
+            #  step change along the transient, another window would not be comparable with `value`)
             eng.analyze_tr(dt, 10)
+            eng.reset()
+            eng.analyze_tr(dt, 2)
             t0 = time.perf_counter()
-            st = eng.analyze_tr(dt, 40)
+            st = eng.analyze_tr(dt, 20)
             el = time.perf_counter() - t0
-            out[str(B)] = {"instance_steps_per_s": st["steps"] / el, "gpu_ms_per_step": st["gpu_ms"] / 40, "n_parts": eng.info()["n_parts"], "steps": 40, "warmup": 10}
+            out[str(B)] = {"instance_steps_per_s": st["steps"] / el, "gpu_ms_per_step": st["gpu_ms"] / 20, "n_parts": eng.info()["n_parts"],
+                           "newton_iters_per_step": st["newton_iters"] / max(1, st["steps"])}
             eng.close()
         except Exception as e:
             out[str(B)] = {"error": str(e)}
