@@ -1,1 +1,1 @@
-#define PE_BUILD_ID "0d989e1dedfa23bf"
+#define PE_BUILD_ID "a8d1181b87c4ad9a"
