@@ -163,9 +163,6 @@ namespace pe
         unsigned char const* q_lane{};
         int const* q_bprog{};               // backward pass of the quad fronts (pe_symbolic.hpp Q_BACK), lists reversed; 1 in quad_back: in use
         int quad_back{};
-        int wave_kernel{};                  // 1: the per-instance wave fronts (the ones the lane-group kernel does not take) run in a launch of their own --
-                                            // one 64-thread workgroup per (instance, part, wavefront list), k_m2_factor_waves -- with a slot of lds_slot doubles
-                                            // that no longer has to fit four times into the parts' workgroup; factor_part then runs cooperative fronts only
         int const *q2_prog{}, *q2_lists{};  // the MID fronts (f_kind 3): second lane-group launch
         unsigned char const* q2_lane{};
         int n_mid{};                        // MID fronts per instance (0: no second launch)

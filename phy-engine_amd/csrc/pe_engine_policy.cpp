@@ -135,14 +135,7 @@ namespace pe_eng PE_ENG_HIDDEN
         V.lds_bstack_off_b = so.wave_m + V.lds_wave_stage_b + 64;
         V.lds_sslot_b = V.lds_bstack_off_b + std::max(1, S.wave_stack);
         {
-            // (wave_kernel -- decided here because the LDS plan depends on it: the lane-group kernel must really be in use, see V.quad below)
-            bool const wave_kernel = so.wave_kernel && S.quad &&
-                                     8 * std::max({static_cast<long long>(S.nnzA), static_cast<long long>(S.factor_doubles), static_cast<long long>(S.arena_doubles),
-                                                   static_cast<long long>(S.n)}) < (1ll << 31);
-            V.wave_kernel = wave_kernel ? 1 : 0;
-            if(so.wave_kernel && !wave_kernel && static_cast<long long>(so.n_waves) * V.lds_slot > (h->lds_limit / 8 - 160) / (so.shared_cu ? std::max(1, 16 / so.n_waves) : 1) - 8)
-                return fail(h, PE_HIP_ERR_INTERNAL, "symbolic analysis: the wave fronts' slot was sized for the wave-front launch, which this circuit cannot use");
-            long long need = wave_kernel ? 0 : static_cast<long long>(so.n_waves) * V.lds_slot;  // (wave_kernel: the slots are another launch's)
+            long long need = static_cast<long long>(so.n_waves) * V.lds_slot;
             need = std::max(need, so.panel_doubles + so.panel_reserve);
             need = std::max(need, static_cast<long long>(so.n_waves) * V.lds_sslot);
             need = std::max(need, static_cast<long long>(V.max_m) + V.lds_coop_stage + so.n_waves * 64);
@@ -157,7 +150,6 @@ namespace pe_eng PE_ENG_HIDDEN
         }
         V.factor_doubles = std::max<long long>(S.factor_doubles, 1);
         V.arena_doubles = std::max<long long>(S.arena_doubles, 1);
-        if(!S.quad) V.wave_kernel = 0;
         // the LDS caps are fixed now: layout of every front + the assembly lists that go with it
         // top levels that leave most CUs without a workgroup run ONE 16-wavefront workgroup per front (k_m2_factor_top_wide): always in
         // the one-workgroup-per-CU geometry (few instances), and on the under-filled levels near the root of a sweep (fronts x instances
@@ -236,7 +228,6 @@ namespace pe_eng PE_ENG_HIDDEN
             // (round 4: with the ancestors' unknowns fetched by two loads + row broadcasts the lane-group backward kernel wins at 128 instances
             //  too -- 1.378 against 1.403 ms per iteration, profiles/r04_ab_runs.log -- : on wherever the lane-group kernel is)
             V.quad_back = (V.quad && knob(h, "QUAD_BACK", 1) != 0) ? 1 : 0;
-            if(!V.quad) V.wave_kernel = 0;
         }
         HIPCHK(h, pool.alloc(V.factor, static_cast<size_t>(V.factor_doubles) * batch));
         HIPCHK(h, pool.alloc(V.arena, static_cast<size_t>(V.arena_doubles) * batch));
@@ -351,23 +342,9 @@ namespace pe_eng PE_ENG_HIDDEN
         long long const lds_doubles = (h->lds_limit / 8 - 160) / resident - 8;  // minus the static LDS of __syncthreads_or & co.
         // a wavefront's slot holds whole fronts of order <= wave_m (pe_front.hpp, FULL mode)
         if(int const ws = env_int("PHY_ENGINE_HIP_WAVE_SLOT", 0); ws > 0) so.wave_slot = ws;  // tuning knob: slot smaller than wave_m needs whole
-        // round 4: with the lane-group kernel the wave fronts left to the per-instance path run in a launch of their own (k_m2_factor_waves:
-        // one wavefront per workgroup, one slot each) -- the slot no longer has to fit n_waves times into the parts' workgroup
-        // Measured and NOT the default (profiles/r04_ab_runs.log r4-8): with the old 10 KB slot the separate launch is a wash (pair 5.59 against
-        // 5.60 ms: dynamic scheduling of the lists gains what the extra launch costs); with a slot that holds the fronts whole (16.6 KB: nine
-        // wavefronts per CU instead of sixteen) it LOSES 3 % -- occupancy again outweighs the cheaper layout.  Knob WAVE_KERNEL=1 for A/B runs.
-        so.wave_kernel = (so.quad && env_int("PHY_ENGINE_HIP_WAVE_KERNEL", 0) != 0) ? 1 : 0;
-        if(so.wave_kernel)
-        {
-            if(env_int("PHY_ENGINE_HIP_WAVE_SLOT", 0) <= 0) so.wave_slot = 0;  // (0: whole fronts up to wave_m)
-            so.wave_slot = std::min<long long>(so.wave_slot, lds_doubles);
-        }
-        else
-        {
         if(so.wave_slot > 0 && so.n_waves * so.wave_slot > lds_doubles) so.wave_slot = 0;
         if(so.wave_slot == 0)
             while(static_cast<long long>(so.n_waves) * so.wave_m * (pe::pe_ld(so.wave_m) + 1) > lds_doubles && so.wave_m > 8) --so.wave_m;
-        }
         so.wave_p = std::min(so.wave_p, so.wave_m);
         so.absorb_m = std::min(so.absorb_m, so.wave_m);
         // large (panel-mode) fronts keep room behind the panels for the right-hand-side column (m doubles) and their

@@ -1096,21 +1096,6 @@ namespace pe
         return true;
     }
 
-    // the per-instance wave fronts of ONE list (part, wavefront w) on a single-wavefront team with its own slot (V.wave_kernel: k_m2_factor_waves)
-    template <class WTeam>
-    PE_DEV bool factor_wave_list(WTeam const& wt, DevView const& V, int b, int part, int w, double* slot, bool fuse)
-    {
-        int const* wp = V.wave_ptr + part * (V.n_waves + 1);
-        int const q1 = wt.uniform(wp[w + 1]);
-        for(int q = wt.uniform(wp[w]); q < q1; ++q)
-        {
-            int const s = wt.uniform(V.wave_list[q]);
-            if(V.quad && V.f_quad[s]) continue;
-            if(!front_factor(wt, V, b, s, slot, V.lds_slot, 0, fuse)) return false;
-        }
-        return true;
-    }
-
     // one PART of the tree (single-workgroup mode: part 0 = everything): wave fronts, then the part's cooperative fronts
     template <class Team>
     PE_DEV bool factor_part(Team const& tm, DevView const& V, int b, int part, double* lds, bool fuse)
@@ -1119,8 +1104,6 @@ namespace pe
         long long const c0 = tm.clock();
         int const* wp = V.wave_ptr + part * (V.n_waves + 1);
         // (quad mode: the wave fronts with V.f_quad were factored by the lane-group kernel, pe_quad.hpp, in the launch before)
-        // (V.wave_kernel: so were the others, by k_m2_factor_waves)
-        if(!V.wave_kernel)
         tm.for_each_wave(
             [&](int w, int lane, int NL)
             {

@@ -688,20 +688,6 @@ namespace pe
         }
     }
 
-    // the per-instance wave fronts (order 33..45, or above a front the lane-group kernel does not take) in a launch of their own: one wavefront
-    // per workgroup = one list of one part of one instance, dynamically scheduled (in the parts' workgroup the four lists of a part wait for the
-    // slowest one: 190 against 135 us) with a slot that holds these fronts WHOLE (in the parts' workgroup four slots share 40 KB: 52 of the 62
-    // such fronts of the 10k mesh ran in the panel layout, whose Schur pulls are 2/3 of their time on a single wavefront)
-    __global__ void __launch_bounds__(64, 4) k_m2_factor_waves(DevView V)
-    {
-        int const b = static_cast<int>(blockIdx.x);
-        if(!V.active[b]) return;
-        int const list = static_cast<int>(blockIdx.y), part = list / V.n_waves, w = list - part * V.n_waves;
-        WaveTeam wt;
-        wt.lane_ = static_cast<int>(threadIdx.x);
-        if(!factor_wave_list(wt, V, b, part, w, pe_lds, true) && threadIdx.x == 0) atomicOr(V.flags + b, 4);
-    }
-
     template <int MINW>
     __global__ void __launch_bounds__(PE_THREADS, MINW) k_m2_factor_top(DevView V, int level, int nlev, int lds_doubles)
     {
@@ -1174,13 +1160,6 @@ namespace pe
                 }
                 hipLaunchKernelGGL(k_m2_factor_quads, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), qlds, st, V);
                 if(V.n_mid > 0) hipLaunchKernelGGL(k_m2_factor_mid, dim3(V.n_quads * V.n_parts * V.n_waves), dim3(64), 0, st, V);
-            }
-            if(V.wave_kernel)
-            {
-                size_t const wl = static_cast<size_t>(V.lds_slot) * sizeof(double);
-                hipError_t const e = set_lds(reinterpret_cast<void const*>(&k_m2_factor_waves), wl);
-                if(e != hipSuccess) return e;
-                hipLaunchKernelGGL(k_m2_factor_waves, dim3(B, V.n_parts * V.n_waves), dim3(64), wl, st, V);
             }
             hipLaunchKernelGGL(k_m2_factor_parts<MINW>, dim3(B, V.n_parts), dim3(T), lds, st, V);
             if(ev1) (void)hipEventRecord(ev1, st);

@@ -38,7 +38,6 @@ namespace pe
         // wavefront in its own LDS slot; larger fronts are COOPERATIVE: the whole workgroup, pivot panels in LDS
         int wave_m{48};
         int wave_p{24};
-        int wave_kernel{0};       // 1: the per-instance wave fronts run in a launch of their own (one wavefront per workgroup: the slot is that launch's)
         long long wave_slot{0};   // LDS doubles of one wavefront's slot; 0: (pe_ld(wave_m) + 1) * wave_m, i.e. every wave front whole.
                                   // Smaller: fronts up to wave_m whose image does not fit run in the panel layout, if their panels fit
         int absorb_m{48};         // a parent absorbs any child while the merged front order stays <= absorb_m (clamped to wave_m)

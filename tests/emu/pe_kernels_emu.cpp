@@ -279,14 +279,6 @@ namespace pe
             (void)rhs;
         }
         if(do_factor) emu_factor_quads(V);  // (a launch of its own on the device, between the stamp and the per-instance parts)
-        if(do_factor && V.wave_kernel)      // (k_m2_factor_waves: every list of every part of every active instance on its own slot)
-        {
-            std::vector<double> slot(static_cast<size_t>(V.lds_slot) + 1);
-            for(int b = 0; b < V.batch; ++b)
-                if(V.active[b])
-                    for(int list = 0; list < V.n_parts * V.n_waves; ++list)
-                        if(!factor_wave_list(SerialTeam{1}, V, b, list / V.n_waves, list % V.n_waves, slot.data(), true)) V.flags[b] |= 4;
-        }
         for(int b = 0; b < V.batch; ++b)
         {
             if(!V.active[b]) continue;
