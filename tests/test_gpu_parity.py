@@ -893,3 +893,65 @@ e.close()
         assert np.array_equal(out[name][1], out["default"][1]), name
         assert np.array_equal(out[name][0], out["default"][0]), name   # bit for bit
     assert len(set(out["default"][1].tolist())) > 1 or out["default"][1].min() > 12   # (the instances do not move in lockstep)
+
+
+def test_ac_of_the_diode_mesh_against_the_oracle(eng, oracle_mod):
+    """Small-signal AC at mesh scale (the four AC goldens have 3-8 nodes): the 32 x 32 diode mesh -- 1 025 nodes, 128 junctions linearised at their
+    operating point, the VAC phasor through 50 ohm -- at three frequencies around the mesh's corner (1 / RC = 1e9 rad/s), a batch of two seeds,
+    against the oracle's complex sparse LU (oracle/pe_oracle.py analyze_ac, pinned to the reference's AC fixtures at 1e-9).  Tolerance as for
+    the AC goldens: 1e-9 + 1e-6 |x|."""
+    omegas = [1e7, 1e9, 3e10]
+    deck, r, c = pe.deck.rc_mesh_params(32, 32, [21, 22], True)
+    eng.set_options(g_min=1e-12)
+    eng.load_deck(deck, batch=2, overrides={"R": r[:, :, None], "C": c[:, :, None]})
+    eng.reset()
+    eng.analyze_dc(pe.ffi.MODE_OP)
+    got = []
+    for w in omegas:
+        x, rc = eng.analyze_ac(w)
+        assert rc == 0
+        got.append(x.copy())
+    for k, seed in enumerate((21, 22)):
+        o = oracle_mod.Oracle(pe.deck.rc_mesh(32, 32, seed, True))
+        o.g_min = 1e-12
+        want = o.analyze_ac(omegas, acop=True)
+        for i in range(len(omegas)):
+            assert want[i] is not None
+            assert np.all(np.abs(got[i][k] - want[i]) <= 1e-9 + 1e-6 * np.abs(want[i])), (seed, omegas[i], np.max(np.abs(got[i][k] - want[i])))
+
+
+def test_solve_csr_complex_seam_at_mesh_size(eng, oracle_mod):
+    """The complex seam on the 10k-node mesh's AC system (G + j omega C: 10 002 complex unknowns = 20 004 real ones, fronts of a few hundred rows
+    in the real-equivalent form): residual at rounding level, agreement with a CPU complex LU, linearity in the right-hand side, and a second
+    frequency on the cached pattern (the susceptances move by 100 x: the cached pivot order must either hold or be re-made)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    mo = oracle_mod.Oracle(pe.deck.rc_mesh(100, 100, 2, False))
+    mo.update_tr_step(1e-10)
+    mo.t = 1e-10
+    A, b = mo.assemble("TR")
+    A = A.tocsr()
+    A.sort_indices()
+    G = A.copy()
+    rng = np.random.default_rng(11)
+    bz = b.astype(complex) + 1j * 1e-3 * rng.standard_normal(len(b))
+
+    def system(scale):
+        # the diagonal carries conductance + companion: move a share of it into the imaginary part (a susceptance), scaled per frequency
+        d = G.diagonal()
+        Z = G.astype(complex).tolil()
+        Z.setdiag(d * (0.6 + 0.4j * scale))
+        Z = Z.tocsr()
+        Z.sort_indices()
+        return Z
+
+    Z1 = system(1.0)
+    x1, tm = eng.solve_csr_complex(Z1.shape[0], Z1.indptr, Z1.indices, Z1.data, bz, copy_pattern=True)
+    assert np.max(np.abs(Z1 @ x1 - bz)) <= 1e-11 * max(1.0, np.max(np.abs(bz)))
+    xr = spla.splu(Z1.tocsc()).solve(bz)
+    assert np.max(np.abs(x1 - xr)) <= 1e-9 * max(1.0, np.max(np.abs(xr)))
+    x2, _ = eng.solve_csr_complex(Z1.shape[0], Z1.indptr, Z1.indices, Z1.data, (2.0 - 3.0j) * bz, copy_pattern=False)
+    assert np.max(np.abs(x2 - (2.0 - 3.0j) * x1)) <= 1e-11 * np.max(np.abs(x2))
+    Z2 = system(100.0)
+    x3, _ = eng.solve_csr_complex(Z2.shape[0], Z2.indptr, Z2.indices, Z2.data, bz, copy_pattern=False)
+    assert np.max(np.abs(Z2 @ x3 - bz)) <= 1e-11 * max(1.0, np.max(np.abs(bz)))
