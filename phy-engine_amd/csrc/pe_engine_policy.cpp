@@ -297,7 +297,6 @@ namespace pe_eng PE_ENG_HIDDEN
         // the wave fronts of a large sweep run four instances per wavefront on the lane-group kernel (pe_quad.hpp): fronts of order
         // <= 32 with <= 16 pivots; larger ones stay with the cooperative phase
         so.quad = (four_per_cu && large && env_int("PHY_ENGINE_HIP_QUAD", 1) != 0) ? 1 : 0;
-        so.quad_max_m = std::clamp(env_int("PHY_ENGINE_HIP_TEST_QUAD_MAX_M", 32), 1, 32);
         if(so.quad)
         {
             // Amalgamation re-swept WITH the lane-group kernel (profiles/sweep_r03_amalgamation.log): a front that absorption grows past

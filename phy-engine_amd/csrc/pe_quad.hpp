@@ -762,13 +762,9 @@ namespace pe
                 int const rs = blk[5], nch = blk[4], rs_next = blk[11];
                 QuadLaneIdx<X> nxt;  // (the last front of a list loads its own data again: no conditional copy of the register block)
                 quad_lane_idx<X>(nxt, V.q_lane + (rs_next ? blk[12] : blk[10]), rs_next ? rs_next : rs, cx.r);
-#if defined(PE_QUAD_RS1)
-                bad = bad | quad_front<X, 1>(V, cx, blk, cur, clk, clkv);  // (experiment: a launch compiled for one row set only)
-#else
                 if(rs == 1) bad = bad | quad_front<X, 1>(V, cx, blk, cur, clk, clkv);
                 else
                     bad = bad | quad_front<X, 2>(V, cx, blk, cur, clk, clkv);
-#endif
                 cur = nxt;
                 blk += 16 + 32 * nch;
             }

@@ -799,7 +799,7 @@ namespace pe
             // lane-group kernel (pe_quad.hpp): two row sets of 16, pivots in the first, one-byte entry indices
             // lane-group kernel (pe_quad.hpp): two row sets of 16, pivots in the first, one-byte entry indices -- a wave front is a QUAD front
             // when its whole subtree satisfies this; the other wave fronts stay with the per-instance wave phase of factor_part
-            fits_quad[s] = fits_quad[s] && m <= opt.quad_max_m && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
+            fits_quad[s] = fits_quad[s] && m <= 32 && S.f_p[s] <= 16 && S.f_asm_ptr[s + 1] - S.f_asm_ptr[s] <= 255 && S.f_child_ptr[s + 1] - S.f_child_ptr[s] <= 16;
             if(fits[s] && opt.wave_slot > 0)
             {
                 // (the slot also holds the right-hand-side column: m doubles behind the image / the panels)

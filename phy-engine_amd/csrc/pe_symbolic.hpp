@@ -48,7 +48,6 @@ namespace pe
         int shared_cu{};                 // the launch geometry keeps several workgroups per CU (128-VGPR kernel variants)
         int quad{};                      // 1: the wave fronts run on the lane-group kernel (pe_quad.hpp) where order <= 32, <= 16 pivots, <= 255 own entries of A, <= 16 children hold for a whole subtree;
                                          // the symbolic analysis then also builds the quad plan below and pads the arena with a zero region
-        int quad_max_m{32};              // (experiment knob) order limit of the lane-group class
         int quad_mid{};                  // 1: fronts of order 33..64 whose subtree qualifies form the MID class (f_kind 3) of a second lane-group launch
         int quad_lds_doubles{};          // LDS doubles per instance of a wavefront's update-matrix stack (0: every update matrix goes through the arena)
         // Second pass of the analysis (pe_engine_policy.cpp analyze_fitting): unknowns whose fronts sat at top levels that run ONE workgroup
