@@ -444,6 +444,20 @@ try:
     raise SystemExit('a singular complex system was accepted')
 except pe.ffi.PeHipError as e:
     assert e.code in (pe.ffi.ERR_SINGULAR, pe.ffi.ERR_INACCURATE), e.code
+# the engine is usable after the refusal; a cached pattern of another size is not reused (the reference's callers pass copy_pattern = false
+# whenever THEY think the pattern is unchanged); an empty system is a no-op; inconsistent sizes are argument errors, not crashes
+D = sp.csr_matrix(np.diag([2.0 + 1.0j, 1.0 - 3.0j, 4.0j])); D.sort_indices()
+x, _ = eng.solve_csr_complex(3, D.indptr, D.indices, D.data, np.array([2.0 + 1.0j, 2.0 - 6.0j, -4.0]), copy_pattern=False)
+assert np.max(np.abs(x - np.array([1.0, 2.0, 1.0j]))) < 1e-14
+x0, _ = eng.solve_csr_complex(0, np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=complex), np.zeros(0, dtype=complex))
+assert x0.shape == (0,)
+import ctypes as C
+l = pe.ffi.lib()
+rp = np.array([0, 1, 3], dtype=np.int32); ci = np.array([0, 0, 1], dtype=np.int32); va = np.ones(6); bb = np.ones(4); xx = np.zeros(4)
+ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)); dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+assert l.pe_hip_solve_csr_complex(eng._h, 2, 2, ip(rp), ip(ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG      # nnz != row_ptr[n]
+assert l.pe_hip_solve_csr_complex(eng._h, 2, 3, ip(rp), ip(ci), None, dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG        # null values
+assert l.pe_hip_solve_csr_complex(None, 2, 3, ip(rp), ip(ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
 
