@@ -787,6 +787,7 @@ int pe_hip_solve_csr_real(pe_hip_engine* h, int n, int nnz, const int* row_ptr, 
     auto& C = h->csr;
     if(copy_pattern || !C.have || C.n != n || C.nnz != nnz)
     {
+        if(char const* bad = csr_pattern_error(n, nnz, row_ptr, col_ind)) return fail(h, PE_HIP_ERR_ARG, std::string("solve_csr_real: ") + bad);
         auto const t0 = clk::now();
         C.have = false;
         C.pool.release();

@@ -193,6 +193,20 @@ static inline int hip_error_code(hipError_t e)
         }                                                                                           \
     } while(0)
 
+// the contract of the solver seam's arrays (the reference builds them that way, circuit.h:1171-1226): 0-based CSR, row_ptr monotone from 0 to nnz,
+// column indices inside [0, n) and strictly increasing inside a row.  Checked once per pattern: everything behind the seam indexes with these numbers.
+static inline char const* csr_pattern_error(int n, int nnz, int const* row_ptr, int const* col_ind)
+{
+    if(n > 0 && (row_ptr[0] != 0 || row_ptr[n] != nnz)) return "row_ptr[0] != 0 or row_ptr[n] != nnz";
+    for(int i = 0; i < n; ++i)
+    {
+        if(row_ptr[i + 1] < row_ptr[i]) return "row_ptr is not monotone";
+        for(int e = row_ptr[i]; e < row_ptr[i + 1]; ++e)
+            if(col_ind[e] < 0 || col_ind[e] >= n || (e > row_ptr[i] && col_ind[e] <= col_ind[e - 1])) return "column indices out of range or not sorted inside a row";
+    }
+    return nullptr;
+}
+
 namespace pe_eng PE_ENG_HIDDEN
 {
     extern thread_local std::string g_create_error;

@@ -55,7 +55,7 @@ int pe_hip_solve_csr_complex(pe_hip_engine* h, int n, int nnz, const int* row_pt
                              double* x_re_im, int copy_pattern, pe_hip_timings* out)
 {
     if(!h || n < 0 || nnz < 0 || !row_ptr || !col_ind || !values_re_im || !b_re_im || !x_re_im) return PE_HIP_ERR_ARG;
-    if(n > 0 && row_ptr[n] != nnz) return fail(h, PE_HIP_ERR_ARG, "solve_csr_complex: row_ptr[n] != nnz");
+    if(n > 0 && (row_ptr[0] != 0 || row_ptr[n] != nnz)) return fail(h, PE_HIP_ERR_ARG, "solve_csr_complex: row_ptr[0] != 0 or row_ptr[n] != nnz");
     if(static_cast<long long>(nnz) * 4 > 0x7fffffffll || static_cast<long long>(n) * 2 > 0x7fffffffll)
         return fail(h, PE_HIP_ERR_ARG, "solve_csr_complex: the real-equivalent system exceeds int32 indices");
     auto const t_total = clk::now();
@@ -66,7 +66,11 @@ int pe_hip_solve_csr_complex(pe_hip_engine* h, int n, int nnz, const int* row_pt
     int const n2 = 2 * n, nnz2 = 4 * nnz;
     // the values of this call in real-equivalent CSR order
     bool const fresh = copy_pattern || !C.have || C.n != n || C.nnz != nnz;
-    if(fresh) real_equivalent_pattern(n, row_ptr, col_ind, C.rp2, C.ci2, C.pos);
+    if(fresh)
+    {
+        if(char const* bad = csr_pattern_error(n, nnz, row_ptr, col_ind)) return fail(h, PE_HIP_ERR_ARG, std::string("solve_csr_complex: ") + bad);
+        real_equivalent_pattern(n, row_ptr, col_ind, C.rp2, C.ci2, C.pos);
+    }
     C.vals.resize(static_cast<size_t>(nnz2));
     for(int e = 0; e < nnz; ++e)
     {

@@ -458,6 +458,10 @@ ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int)); dp = lambda a: a.ctypes.dat
 assert l.pe_hip_solve_csr_complex(eng._h, 2, 2, ip(rp), ip(ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG      # nnz != row_ptr[n]
 assert l.pe_hip_solve_csr_complex(eng._h, 2, 3, ip(rp), ip(ci), None, dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG        # null values
 assert l.pe_hip_solve_csr_complex(None, 2, 3, ip(rp), ip(ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG
+bad_ci = np.array([0, 1, 0], dtype=np.int32)                                                                             # unsorted columns in row 1
+assert l.pe_hip_solve_csr_complex(eng._h, 2, 3, ip(rp), ip(bad_ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG
+far_ci = np.array([0, 0, 7], dtype=np.int32)                                                                             # column out of range
+assert l.pe_hip_solve_csr_complex(eng._h, 2, 3, ip(rp), ip(far_ci), dp(va), dp(bb), dp(xx), 1, None) == pe.ffi.ERR_ARG
 """
     subprocess.run(["python3", "-c", code], check=True, timeout=600)
 
